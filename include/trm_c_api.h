@@ -1,0 +1,199 @@
+/*
+ * trm_c_api.h -- C ABI of libtrm_hip.so, the MI355X (gfx950) Tube Resonance Model.
+ *
+ * This header is the drop-in boundary for ONE path of grrrr/GnuSpeech: the per-sample
+ * Tube Resonance Model loop `-[TRMTubeModel synthesize]` (Frameworks/Tube) and the
+ * data model / output writers on either side of it.  Every entry point names the
+ * reference interface it replaces (file:line relative to the GnuSpeech tree).  The
+ * reference surface is Objective-C; the ABI below is what an Objective-C shim (see
+ * INTEGRATION.md and shim/) binds: plain pointers and sizes, no C++/torch types.
+ *
+ * Threading: handles are independent; calls on one handle are blocking and must not
+ * overlap (same contract as a TRMTubeModel instance, TRMTubeModel.m:133-184).
+ */
+#ifndef TRM_C_API_H
+#define TRM_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Frameworks/Tube/TRMTubeModel.h:6-25 */
+#define TRM_TOTAL_REGIONS        8
+#define TRM_TOTAL_NASAL_SECTIONS 6
+#define TRM_FRAME_VALUES         16   /* TRMParameters.h:9-17: 7 scalars + radius[8] + velum */
+
+/* Frameworks/Tube/TRMInputParameters.h:7-20 */
+enum { TRM_SOUND_FILE_FORMAT_AU = 0, TRM_SOUND_FILE_FORMAT_AIFF = 1, TRM_SOUND_FILE_FORMAT_WAVE = 2 };
+enum { TRM_WAVEFORM_PULSE = 0, TRM_WAVEFORM_SINE = 1 };
+
+/* error codes (the reference returns nil/NO and prints to stderr; TRMTubeModel.m:204-207) */
+enum {
+    TRM_OK             = 0,
+    TRM_EINVAL         = 1,   /* NULL / malformed argument                                  */
+    TRM_EINVAL_LENGTH  = 2,   /* tube length <= 0           (TRMTubeModel.m:204-207 -> nil)   */
+    TRM_EFIR           = 3,   /* FIR design failure         (TRMFIRFilter.m:49-51 -> nil)     */
+    TRM_ENOMEM         = 4,
+    TRM_EHIP           = 5,   /* HIP runtime error; text via trm_last_error()               */
+    TRM_ENODEVICE      = 6,   /* no gfx950 device visible: the product path never falls back */
+    TRM_EIO            = 7,   /* file open / read / write   (TRMDataList.m:45-49 -> NO)       */
+    TRM_EPARSE         = 8,   /* truncated utterance-rate header (TRMDataList.m:53-214)      */
+    TRM_ESILENT        = 9,   /* maximumSampleValue == 0    (TRMTubeModel.m:511 assert)       */
+    TRM_ERANGE         = 10   /* rates outside what the kernels support     */
+};
+
+/* TRMInputParameters (Frameworks/Tube/TRMInputParameters.h:26-54): the 26 utterance-rate
+ * fields, same names, same types (outputRate/controlRate are float in the reference). */
+typedef struct trm_input_params {
+    int32_t outputFileFormat;     /* 0=AU 1=AIFF 2=WAVE                         */
+    float   outputRate;           /* 22050 / 44100                              */
+    float   controlRate;          /* 1-1000 input tables / s                    */
+    double  volume;               /* master volume 0-60 dB                      */
+    int32_t channels;             /* 1 or 2                                     */
+    double  balance;              /* -1..+1                                     */
+    int32_t waveform;             /* 0=pulse 1=sine                             */
+    double  tp;                   /* % glottal pulse rise time                  */
+    double  tnMin;                /* % fall time minimum                        */
+    double  tnMax;                /* % fall time maximum                        */
+    double  breathiness;          /* % glottal source breathiness               */
+    double  length;               /* nominal tube length cm                     */
+    double  temperature;          /* deg C                                      */
+    double  lossFactor;           /* junction loss %                            */
+    double  apScale;              /* aperture scaling radius cm                 */
+    double  mouthCoef;            /* mouth aperture coefficient (Hz)            */
+    double  noseCoef;             /* nose aperture coefficient (Hz)             */
+    double  noseRadius[TRM_TOTAL_NASAL_SECTIONS]; /* [0] unused (TRMDataList.m:178) */
+    double  throatCutoff;         /* Hz                                         */
+    double  throatVol;            /* dB                                         */
+    int32_t usesModulation;       /* pulse modulation of noise                  */
+    double  mixOffset;            /* noise crossmix offset dB                   */
+} trm_input_params;
+
+/* TRMParameters (Frameworks/Tube/TRMParameters.h:9-17): one control-rate frame,
+ * 16 doubles in .trm file column order (TRMDataList.m:223-233). */
+typedef struct trm_parameters {
+    double glottalPitch;
+    double glottalVolume;
+    double aspirationVolume;
+    double fricationVolume;
+    double fricationPosition;
+    double fricationCenterFrequency;
+    double fricationBandwidth;
+    double radius[TRM_TOTAL_REGIONS];
+    double velum;
+} trm_parameters;
+
+/* Values TRMTubeModel derives in -initWithInputData: (TRMTubeModel.m:196-241) and
+ * TRMSampleRateConverter -initWithInputRate:outputRate: (TRMSampleRateConverter.m:69-104);
+ * what -printInputData prints (TRMTubeModel.m:595-605). */
+typedef struct trm_derived {
+    int32_t  controlPeriod;
+    int32_t  sampleRate;            /* tube rate */
+    double   actualTubeLength;
+    double   sampleRateRatio;
+    uint32_t timeRegisterIncrement;
+    uint32_t phaseIncrement;        /* down-sampling only */
+    int32_t  padSize;
+    int32_t  firTaps;               /* oscillator FIR taps (49 for the shipped beta/gamma/cutoff) */
+} trm_derived;
+
+const char *trm_strerror(int code);
+const char *trm_last_error(void);          /* thread-local detail text of the last failure */
+
+/* ------------------------------------------------------------------------------------
+ * Data model + text format: TRMDataList (Frameworks/Tube/TRMDataList.m:32-40, 43-247).
+ * 26 header lines (first token of each), then rows of 16 values; the file path doubles
+ * the last row (TRMDataList.m:239-241).  *frames is malloc'd; release with trm_free().
+ * ------------------------------------------------------------------------------------ */
+int  trm_data_list_read_file(const char *path, trm_input_params *params,
+                             trm_parameters **frames, size_t *nframes);
+/* Writer of the same format: MMSynthesisParameters -parameterString
+ * (MonetModel/MMSynthesisParameters.m:278-310) + TRMParameters -valuesString
+ * (TRMParameters.m:26-43); what Monet dumps to /tmp/Monet.parameters. */
+int  trm_data_list_write_file(const char *path, const trm_input_params *params,
+                              const trm_parameters *frames, size_t nframes);
+void trm_free(void *p);
+
+/* ------------------------------------------------------------------------------------
+ * TRMTubeModel (Frameworks/Tube/TRMTubeModel.h:29-40): one tube per utterance.
+ * ------------------------------------------------------------------------------------ */
+typedef struct trm_tube trm_tube;
+
+/* -initWithInputData: (TRMTubeModel.m:186-260).  device < 0 => current HIP device. */
+int  trm_tube_create(const trm_input_params *params, int device, trm_tube **tube);
+void trm_tube_destroy(trm_tube *tube);
+int  trm_tube_derived(const trm_tube *tube, trm_derived *out);
+
+/* -synthesize (TRMTubeModel.m:272-361) over inputData.values = frames[0..nframes):
+ * N frames -> N-1 control periods; 0 frames is a silent no-op (:274-277). */
+int  trm_tube_synthesize(trm_tube *tube, const trm_parameters *frames, size_t nframes);
+
+/* TRMSampleRateConverter numberSamples / maximumSampleValue / resampledData
+ * (TRMSampleRateConverter.m:206-214,312-315).  The pointer stays valid until the next
+ * synthesize or destroy. */
+size_t       trm_tube_number_samples(const trm_tube *tube);
+double       trm_tube_maximum_sample_value(const trm_tube *tube);
+const float *trm_tube_samples(const trm_tube *tube);
+
+/* -saveOutputToFile:error: (TRMTubeModel.m:365-490): scale, balance, int16, AU/AIFF/WAVE
+ * container chosen by params.outputFileFormat. */
+int  trm_tube_save_output_to_file(trm_tube *tube, const char *filename);
+/* -generateWAVData (TRMTubeModel.m:509-593).  Call with buf==NULL to get the size. */
+int  trm_tube_generate_wav_data(trm_tube *tube, uint8_t *buf, size_t cap, size_t *len);
+
+/* ------------------------------------------------------------------------------------
+ * Batch entry (no reference equivalent: the reference builds one tube per utterance,
+ * TRMSynthesizer.m:118-136; GnuTTSServer calls it once per utterance).  One call runs
+ * V independent tubes that share one trm_input_params, one tube per lane.
+ * ------------------------------------------------------------------------------------ */
+typedef struct trm_batch trm_batch;
+
+int  trm_batch_create(const trm_input_params *params, int device, trm_batch **batch);
+void trm_batch_destroy(trm_batch *batch);
+int  trm_batch_derived(const trm_batch *batch, trm_derived *out);
+
+/* Output samples a voice of `nframes` frames produces (exact, integer-only). */
+size_t trm_batch_samples_for_frames(const trm_batch *batch, size_t nframes);
+
+/* Host-buffer form: frames = concatenated rows, voice v owns rows
+ * [frame_offset[v], frame_offset[v]+nframes[v]); out receives voice v's fp32 PCM at
+ * out + out_offset[v] (caller sizes it with trm_batch_samples_for_frames);
+ * number_samples[v] / max_sample[v] are the converter's numberSamples and
+ * maximumSampleValue.  Includes H2D/D2H. */
+int  trm_batch_synthesize_host(trm_batch *batch, size_t nvoices,
+                               const float *frames, const uint64_t *frame_offset,
+                               const uint32_t *nframes,
+                               float *out, const uint64_t *out_offset,
+                               uint32_t *number_samples, float *max_sample);
+
+/* Device-buffer form (all pointers are HIP device pointers on the batch's device;
+ * stream is a hipStream_t or NULL).  Asynchronous on `stream`. */
+int  trm_batch_synthesize_device(trm_batch *batch, size_t nvoices,
+                                 const float *d_frames, const uint64_t *d_frame_offset,
+                                 const uint32_t *d_nframes, uint32_t max_nframes,
+                                 float *d_out, const uint64_t *d_out_offset,
+                                 uint32_t *d_number_samples, float *d_max_sample,
+                                 void *stream);
+
+/* Output normalisation on device, TRMTubeModel.m:370-389,420-484: int16 mono/stereo
+ * from fp32 PCM with per-voice scale = 32767/max * amplitude(volume). */
+int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,
+                                     const float *d_pcm, const uint64_t *d_out_offset,
+                                     const uint32_t *d_number_samples, const float *d_max_sample,
+                                     int16_t *d_int16, int for_wav_data, void *stream);
+
+/* Average device time (ms) of the tube kernel launches since the last call, measured
+ * with hipEvents on the launch stream; resets the accumulator.  Used by bench.py. */
+int  trm_batch_kernel_time_ms(trm_batch *batch, double *total_ms, uint32_t *launches);
+
+/* Library / device identification. */
+int  trm_device_count(void);
+const char *trm_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRM_C_API_H */

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the REFERENCE's own C tube.
+
+Runs oracle/_ref/tube_ref (Applications/TRAcT/tube.c compiled in place from /root/reference
+by oracle/Makefile, driven by oracle/ref_driver.c) on every case of tests/cases.golden_cases()
+and freezes what the reference computed: tube-rate doubles, converter output (fp32, as tube.c's
+dataEmpty emits it), numberSamples, maximumSampleValue, FIR taps, derived constants.
+Only runs where /root/reference exists; the .npz files are the committed fixtures.
+
+    make -C oracle && python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import cases  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+
+def main():
+    if not O.have_ref():
+        sys.exit("oracle/_ref/tube_ref missing: run `make -C oracle` where /root/reference exists")
+    h_saved = False
+    for name, (pd, frames) in cases.golden_cases().items():
+        p = O.InputParams.from_dict(pd)
+        with tempfile.TemporaryDirectory() as d:
+            r = O.run_ref(p, frames, d)
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            params_json=np.array(json.dumps(pd)),
+            frames=np.asarray(frames, dtype=np.float64),
+            tubeSamples=r["tubeSamples"],
+            samples_f32=r["samples_f32"],
+            numberSamples=np.int64(r["numberSamples"]),
+            maximumSampleValue=np.float64(r["maximumSampleValue"]),
+            firCoef=r["firCoef"],
+            derived=np.array([r["controlPeriod"], r["sampleRate"], r["padSize"], r["firTaps"],
+                              r["timeRegisterIncrement"], r["phaseIncrement"]], dtype=np.int64),
+            tap_err=np.float64(r["tap_err"]),
+        )
+        if not h_saved:
+            np.savez_compressed(os.path.join(HERE, "src_tables.npz"), h=r["h"], deltaH=r["deltaH"])
+            h_saved = True
+        print("%-26s frames=%4d tube=%6d out=%6d max=%.6g" % (
+            name, len(frames), len(r["tubeSamples"]), r["numberSamples"], r["maximumSampleValue"]))
+
+
+if __name__ == "__main__":
+    main()

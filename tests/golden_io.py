@@ -1,0 +1,23 @@
+"""Loader for the committed reference-generated fixtures in tests/golden/*.npz."""
+import json
+import os
+
+import numpy as np
+
+import oracle_lib as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASE_NAMES = ["tract_vowel_1s", "monet_vowel_44k", "monet_vowel_22k", "gnuspeech_input_22k",
+              "gnuspeech_window_44k", "sine_nomod", "frication_sweep", "short_tube_downsample",
+              "female_15cm_stereo"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    pd = json.loads(str(z["params_json"]))
+    g = {k: z[k] for k in z.files if k != "params_json"}
+    g["params_dict"] = pd
+    g["params"] = O.InputParams.from_dict(pd)
+    g["numberSamples"] = int(g["numberSamples"])
+    g["maximumSampleValue"] = float(g["maximumSampleValue"])
+    return g
