@@ -1,0 +1,117 @@
+"""Batch front end: V independent tubes, one per GPU lane, sharing one TRMInputParameters.
+
+torch is used only as the owner of device memory and streams (plumbing): the kernels are
+libtrm_hip.so's.  Layout in HBM:
+    frames   fp32 [sum nframes][16]      voice v owns rows frame_offset[v] .. +nframes[v]
+    pcm      fp32 [sum nsamples]         voice v's output at out_offset[v]
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._capi import TrmDerived, check, lib
+
+
+class TRMBatch:
+    def __init__(self, inputParameters, device=-1):
+        self._h = C.c_void_p()
+        self.inputParameters = inputParameters
+        check(lib().trm_batch_create(C.byref(inputParameters.c), device, C.byref(self._h)))
+        d = TrmDerived()
+        check(lib().trm_batch_derived(self._h, C.byref(d)))
+        self.derived = {k: getattr(d, k) for k, _ in TrmDerived._fields_}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().trm_batch_destroy(h)
+            self._h = None
+
+    def samples_for_frames(self, nframes):
+        return lib().trm_batch_samples_for_frames(self._h, int(nframes))
+
+    # -------------------------------------------------------------- host buffers (incl. H2D / D2H)
+    def synthesize(self, voices):
+        """voices: list of [n_v,16] arrays (ragged allowed).  Returns (list of fp32 PCM arrays,
+        numberSamples uint32[V], maximumSampleValue float32[V])."""
+        V = len(voices)
+        nfr = np.array([len(v) for v in voices], dtype=np.uint32)
+        foff = np.zeros(max(1, V), dtype=np.uint64)
+        if V > 1:
+            foff[1:V] = np.cumsum(nfr[:-1], dtype=np.uint64)
+        frames = np.zeros((max(1, int(nfr.sum())), 16), dtype=np.float32)
+        for v, fr in enumerate(voices):
+            if len(fr):
+                frames[int(foff[v]):int(foff[v]) + len(fr)] = np.asarray(fr, dtype=np.float32)
+        nout = np.array([self.samples_for_frames(n) for n in nfr], dtype=np.uint64)
+        ooff = np.zeros(max(1, V), dtype=np.uint64)
+        if V > 1:
+            ooff[1:V] = np.cumsum(nout[:-1], dtype=np.uint64)
+        out = np.zeros(max(1, int(nout.sum())), dtype=np.float32)
+        ns = np.zeros(max(1, V), dtype=np.uint32)
+        mx = np.zeros(max(1, V), dtype=np.float32)
+        nfr_c = np.ascontiguousarray(nfr if V else np.zeros(1, np.uint32))
+        check(lib().trm_batch_synthesize_host(self._h, V, frames.ctypes.data, foff.ctypes.data, nfr_c.ctypes.data,
+                                              out.ctypes.data, ooff.ctypes.data, ns.ctypes.data, mx.ctypes.data))
+        pcm = [out[int(ooff[v]):int(ooff[v]) + int(ns[v])] for v in range(V)]
+        return pcm, ns[:V], mx[:V]
+
+    # -------------------------------------------------------------- device buffers (torch tensors)
+    def prepare_device(self, frames, device="cuda"):
+        """Upload a batch once.  frames: [V,N,16] array (uniform) or list of [n_v,16] (ragged)."""
+        import torch
+        if isinstance(frames, np.ndarray) and frames.ndim == 3:
+            V, N = frames.shape[:2]
+            nfr = np.full(V, N, dtype=np.int64)
+            flat = np.ascontiguousarray(frames.reshape(V * N, 16), dtype=np.float32)
+        else:
+            V = len(frames)
+            nfr = np.array([len(v) for v in frames], dtype=np.int64)
+            flat = (np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1, 16) for v in frames])
+                    if V else np.zeros((0, 16), np.float32))
+        foff = np.zeros(max(1, V), dtype=np.int64)
+        if V > 1:
+            foff[1:V] = np.cumsum(nfr[:-1])
+        lut = {int(n): self.samples_for_frames(int(n)) for n in np.unique(nfr)}
+        nout_v = np.array([lut[int(n)] for n in nfr], dtype=np.int64)
+        ooff = np.zeros(max(1, V), dtype=np.int64)
+        if V > 1:
+            ooff[1:V] = np.cumsum(nout_v[:-1])
+        dev = torch.device(device)
+        return {
+            "V": V, "max_nframes": int(nfr.max()) if V else 0, "total_out": int(nout_v.sum()),
+            "nout": nout_v, "out_offset_host": ooff, "nframes_host": nfr,
+            "frames": torch.from_numpy(flat if flat.size else np.zeros((1, 16), np.float32)).to(dev),
+            "frame_offset": torch.from_numpy(foff).to(dev),
+            "nframes": torch.from_numpy(nfr.astype(np.int32) if V else np.zeros(1, np.int32)).to(dev),
+            "out_offset": torch.from_numpy(ooff).to(dev),
+            "out": torch.zeros(max(1, int(nout_v.sum())), dtype=torch.float32, device=dev),
+            "number_samples": torch.zeros(max(1, V), dtype=torch.int32, device=dev),
+            "max_sample": torch.zeros(max(1, V), dtype=torch.float32, device=dev),
+        }
+
+    def synthesize_device(self, st, stream=None):
+        """One pass of the hot path over a resident batch; asynchronous on `stream`
+        (default: torch's current stream)."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        check(lib().trm_batch_synthesize_device(
+            self._h, st["V"], st["frames"].data_ptr(), st["frame_offset"].data_ptr(), st["nframes"].data_ptr(),
+            st["max_nframes"], st["out"].data_ptr(), st["out_offset"].data_ptr(), st["number_samples"].data_ptr(),
+            st["max_sample"].data_ptr(), C.c_void_p(s.cuda_stream)))
+
+    def scale_to_int16_device(self, st, for_wav_data=False, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        ch = 2 if self.inputParameters.channels == 2 else 1
+        pcm16 = torch.zeros(max(1, st["total_out"] * ch), dtype=torch.int16, device=st["out"].device)
+        check(lib().trm_batch_scale_to_int16_device(
+            self._h, st["V"], st["out"].data_ptr(), st["out_offset"].data_ptr(), st["number_samples"].data_ptr(),
+            st["max_sample"].data_ptr(), pcm16.data_ptr(), int(for_wav_data), C.c_void_p(s.cuda_stream)))
+        return pcm16
+
+    def kernel_time_ms(self):
+        t = C.c_double()
+        n = C.c_uint32()
+        check(lib().trm_batch_kernel_time_ms(self._h, C.byref(t), C.byref(n)))
+        return t.value, n.value

@@ -1,0 +1,455 @@
+// trm_capi.cc -- implementation of include/trm_c_api.h on top of the HIP kernels.
+//
+// The product path is HIP only: if no gfx950 device is usable every synthesis entry point
+// fails with TRM_ENODEVICE / TRM_EHIP.  There is no CPU fallback here and nothing in this
+// library links or loads oracle/.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/trm_c_api.h"
+#include "trm_io.h"
+#include "trm_kernels.h"
+#include "trm_setup.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(TRM_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int reserve(size_t n)
+    {
+        if (n <= cap) return TRM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(TRM_EHIP, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return TRM_OK;
+    }
+};
+
+}  // namespace
+
+struct trm_batch {
+    trm_input_params params;
+    trm::Const c;
+    trm_derived d;
+    int device = 0;
+    hipStream_t stream = nullptr;        // used by the host-buffer entry points
+    trm::Const *dConst = nullptr;
+    float *dRows = nullptr, *dSine = nullptr;
+    DevBuf<float> dNoise;
+    double *dNoiseState = nullptr;
+    uint32_t noiseLen = 0;
+    // host-form staging
+    DevBuf<float> dFrames, dOut, dMax;
+    DevBuf<uint64_t> dFrameOff, dOutOff;
+    DevBuf<uint32_t> dNFrames, dNSamples;
+    // kernel timing (hipEvents on the launch stream)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    bool timing = true;
+};
+
+struct trm_tube {
+    trm_batch *b = nullptr;
+    std::vector<float> samples;
+    uint32_t numberSamples = 0;
+    float maxSample = 0.f;
+};
+
+extern "C" {
+
+const char *trm_strerror(int code)
+{
+    switch (code) {
+    case TRM_OK: return "ok";
+    case TRM_EINVAL: return "invalid argument";
+    case TRM_EINVAL_LENGTH: return "illegal tube length";
+    case TRM_EFIR: return "oscillator FIR design failed";
+    case TRM_ENOMEM: return "out of memory";
+    case TRM_EHIP: return "HIP runtime error";
+    case TRM_ENODEVICE: return "no usable gfx950 device";
+    case TRM_EIO: return "file i/o error";
+    case TRM_EPARSE: return "truncated input file";
+    case TRM_ESILENT: return "maximum sample value is zero";
+    case TRM_ERANGE: return "rates outside the supported range";
+    }
+    return "unknown";
+}
+
+const char *trm_last_error(void) { return g_err.c_str(); }
+
+int trm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *trm_build_info(void) { return "libtrm_hip gfx950 (one tube per lane, wave64) " __DATE__; }
+
+void trm_free(void *p) { free(p); }
+
+// ------------------------------------------------------------------ batch object
+int trm_batch_create(const trm_input_params *params, int device, trm_batch **out)
+{
+    if (!params || !out) return fail(TRM_EINVAL, "null argument");
+    *out = nullptr;
+    trm::Const c;
+    trm_derived d;
+    int rc = trm::build_const(*params, c, d);
+    if (rc != TRM_OK) {
+        if (rc == TRM_EINVAL_LENGTH) fprintf(stderr, "Illegal tube length: %g\n", params->length);   // TRMTubeModel.m:205
+        return fail(rc, "%s", trm_strerror(rc));
+    }
+    if (!c.upsample)
+        return fail(TRM_ERANGE, "tube rate %d Hz above the output rate %g Hz: the down-sampling converter branch "
+                                "(TRMSampleRateConverter.m:234-297) is not on the HIP path yet", d.sampleRate, (double)params->outputRate);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TRM_ENODEVICE, "no HIP device visible");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) return fail(TRM_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TRM_ENODEVICE, "device %d is %s; libtrm_hip carries gfx950 code only", device, prop.gcnArchName);
+
+    trm_batch *b = new (std::nothrow) trm_batch();
+    if (!b) return fail(TRM_ENOMEM, "trm_batch");
+    b->params = *params;
+    b->c = c;
+    b->d = d;
+    b->device = device;
+    std::vector<float> rows, sine;
+    trm::build_src_rows(rows);
+    trm::build_sine_table(sine);
+    hipError_t e;
+#define B_TRY(expr)                                                              \
+    if ((e = (expr)) != hipSuccess) {                                            \
+        trm_batch_destroy(b);                                                    \
+        return fail(TRM_EHIP, "%s: %s", #expr, hipGetErrorString(e));            \
+    }
+    B_TRY(hipStreamCreate(&b->stream));
+    B_TRY(hipMalloc((void **)&b->dConst, sizeof(trm::Const)));
+    B_TRY(hipMemcpy(b->dConst, &b->c, sizeof(trm::Const), hipMemcpyHostToDevice));
+    B_TRY(hipMalloc((void **)&b->dRows, rows.size() * sizeof(float)));
+    B_TRY(hipMemcpy(b->dRows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+    B_TRY(hipMalloc((void **)&b->dSine, sine.size() * sizeof(float)));
+    B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
+    B_TRY(hipMalloc((void **)&b->dNoiseState, 2 * sizeof(double)));
+#undef B_TRY
+    *out = b;
+    return TRM_OK;
+}
+
+void trm_batch_destroy(trm_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (b->dConst) (void)hipFree(b->dConst);
+    if (b->dRows) (void)hipFree(b->dRows);
+    if (b->dSine) (void)hipFree(b->dSine);
+    if (b->dNoiseState) (void)hipFree(b->dNoiseState);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int trm_batch_derived(const trm_batch *b, trm_derived *out)
+{
+    if (!b || !out) return fail(TRM_EINVAL, "null argument");
+    *out = b->d;
+    return TRM_OK;
+}
+
+size_t trm_batch_samples_for_frames(const trm_batch *b, size_t nframes)
+{
+    if (!b || nframes == 0) return 0;                                   // TRMTubeModel.m:274-277
+    return (size_t)trm::count_outputs(b->d, (uint64_t)(nframes - 1) * (uint64_t)b->d.controlPeriod);
+}
+
+// The voice-independent noise sequence is generated on the device (fp64, one lane) and cached;
+// it only ever grows.  `need` = tube samples incl. the flush tail.
+static int ensure_noise(trm_batch *b, uint32_t need, hipStream_t stream)
+{
+    if (need <= b->noiseLen) return TRM_OK;
+    uint32_t newLen = need + need / 2 + 4096;
+    if (newLen > b->dNoise.cap) {
+        // grow: regenerate from the start into a fresh buffer (serial recurrence, ~10 ns/sample)
+        HIP_TRY(hipStreamSynchronize(stream));
+        int rc = b->dNoise.reserve(newLen);
+        if (rc) return rc;
+        b->noiseLen = 0;
+    }
+    if (b->noiseLen == 0) {
+        const double init[2] = {0.7892347, 0.0};                        // TRMUtility.m:72-77, TRMTubeModel.m:235
+        HIP_TRY(hipMemcpyAsync(b->dNoiseState, init, sizeof init, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));                          // init[] is a stack temporary
+    }
+    uint32_t to = (uint32_t)b->dNoise.cap;
+    HIP_TRY(trm::launch_noise(b->dNoise.p, b->noiseLen, to, b->dNoiseState, stream));
+    b->noiseLen = to;
+    return TRM_OK;
+}
+
+int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_frames, const uint64_t *d_frame_offset,
+                                const uint32_t *d_nframes, uint32_t max_nframes, float *d_out,
+                                const uint64_t *d_out_offset, uint32_t *d_number_samples, float *d_max_sample,
+                                void *stream_)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (nvoices == 0) return TRM_OK;
+    if (!d_frames || !d_frame_offset || !d_nframes || !d_out || !d_out_offset || !d_number_samples || !d_max_sample)
+        return fail(TRM_EINVAL, "null device pointer");
+    if (nvoices > 0xFFFFFFFFull - 64) return fail(TRM_EINVAL, "too many voices");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(b->device));
+    uint64_t ntubeMax = max_nframes > 0 ? (uint64_t)(max_nframes - 1) * (uint64_t)b->d.controlPeriod : 0;
+    if (ntubeMax + 64 > 0x7FFFFFFFull) return fail(TRM_ERANGE, "utterance too long");
+    int rc = ensure_noise(b, (uint32_t)ntubeMax + 2u * (uint32_t)b->d.padSize + 8u, stream);
+    if (rc) return rc;
+    trm::TubeArgs a;
+    a.frames = d_frames;
+    a.frame_offset = d_frame_offset;
+    a.nframes = d_nframes;
+    a.out = d_out;
+    a.out_offset = d_out_offset;
+    a.number_samples = d_number_samples;
+    a.max_sample = d_max_sample;
+    a.lp_noise = b->dNoise.p;
+    a.src_rows = b->dRows;
+    a.sine = b->dSine;
+    a.nvoices = (uint32_t)nvoices;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (b->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+    HIP_TRY(trm::launch_tube(b->dConst, a, stream));
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(e1, stream));
+        b->events.emplace_back(e0, e1);
+    }
+    return TRM_OK;
+}
+
+int trm_batch_kernel_time_ms(trm_batch *b, double *total_ms, uint32_t *launches)
+{
+    if (!b || !total_ms || !launches) return fail(TRM_EINVAL, "null argument");
+    double sum = 0.0;
+    uint32_t n = 0;
+    for (auto &ev : b->events) {
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        sum += ms;
+        n++;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    b->events.clear();
+    *total_ms = sum;
+    *launches = n;
+    return TRM_OK;
+}
+
+int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                              const uint32_t *nframes, float *out, const uint64_t *out_offset,
+                              uint32_t *number_samples, float *max_sample)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (nvoices == 0) return TRM_OK;
+    if (!frames || !frame_offset || !nframes || !out || !out_offset || !number_samples || !max_sample)
+        return fail(TRM_EINVAL, "null pointer");
+    HIP_TRY(hipSetDevice(b->device));
+    uint64_t frameRows = 0, outEnd = 0;
+    uint32_t maxFrames = 0;
+    for (size_t v = 0; v < nvoices; v++) {
+        uint64_t fe = frame_offset[v] + nframes[v];
+        if (fe > frameRows) frameRows = fe;
+        uint64_t oe = out_offset[v] + trm_batch_samples_for_frames(b, nframes[v]);
+        if (oe > outEnd) outEnd = oe;
+        if (nframes[v] > maxFrames) maxFrames = nframes[v];
+    }
+    if (frameRows == 0) frameRows = 1;
+    int rc;
+    if ((rc = b->dFrames.reserve(frameRows * 16)) || (rc = b->dOut.reserve(outEnd + 1)) ||
+        (rc = b->dFrameOff.reserve(nvoices)) || (rc = b->dOutOff.reserve(nvoices)) ||
+        (rc = b->dNFrames.reserve(nvoices)) || (rc = b->dNSamples.reserve(nvoices)) || (rc = b->dMax.reserve(nvoices)))
+        return rc;
+    hipStream_t s = b->stream;
+    HIP_TRY(hipMemcpyAsync(b->dFrames.p, frames, frameRows * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->dFrameOff.p, frame_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->dOutOff.p, out_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->dNFrames.p, nframes, nvoices * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    rc = trm_batch_synthesize_device(b, nvoices, b->dFrames.p, b->dFrameOff.p, b->dNFrames.p, maxFrames, b->dOut.p,
+                                     b->dOutOff.p, b->dNSamples.p, b->dMax.p, s);
+    if (rc) return rc;
+    if (outEnd) HIP_TRY(hipMemcpyAsync(out, b->dOut.p, outEnd * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return TRM_OK;
+}
+
+int trm_batch_scale_to_int16_device(trm_batch *b, size_t nvoices, const float *d_pcm, const uint64_t *d_out_offset,
+                                    const uint32_t *d_number_samples, const float *d_max_sample, int16_t *d_int16,
+                                    int for_wav_data, void *stream_)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (nvoices == 0) return TRM_OK;
+    if (!d_pcm || !d_out_offset || !d_number_samples || !d_max_sample || !d_int16) return fail(TRM_EINVAL, "null device pointer");
+    HIP_TRY(hipSetDevice(b->device));
+    trm::ScaleArgs s;
+    s.pcm = d_pcm;
+    s.out_offset = d_out_offset;
+    s.number_samples = d_number_samples;
+    s.max_sample = d_max_sample;
+    s.pcm16 = d_int16;
+    s.volumeAmp = trm::io_amplitude(b->params.volume);
+    s.balance = b->params.balance;
+    s.channels = b->params.channels;
+    s.forWavData = for_wav_data != 0;
+    HIP_TRY(trm::launch_int16(s, (uint32_t)nvoices, (hipStream_t)stream_));
+    return TRM_OK;
+}
+
+// ------------------------------------------------------------------ TRMTubeModel
+int trm_tube_create(const trm_input_params *params, int device, trm_tube **out)
+{
+    if (!params || !out) return fail(TRM_EINVAL, "null argument");
+    *out = nullptr;
+    trm_batch *b = nullptr;
+    int rc = trm_batch_create(params, device, &b);
+    if (rc) return rc;
+    trm_tube *t = new (std::nothrow) trm_tube();
+    if (!t) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_tube"); }
+    t->b = b;
+    *out = t;
+    return TRM_OK;
+}
+
+void trm_tube_destroy(trm_tube *t)
+{
+    if (!t) return;
+    trm_batch_destroy(t->b);
+    delete t;
+}
+
+int trm_tube_derived(const trm_tube *t, trm_derived *out)
+{
+    if (!t) return fail(TRM_EINVAL, "null tube");
+    return trm_batch_derived(t->b, out);
+}
+
+int trm_tube_synthesize(trm_tube *t, const trm_parameters *frames, size_t nframes)
+{
+    if (!t || (nframes && !frames)) return fail(TRM_EINVAL, "null argument");
+    t->samples.clear();
+    t->numberSamples = 0;
+    t->maxSample = 0.f;
+    if (nframes == 0) return TRM_OK;                                    // TRMTubeModel.m:274-277
+    if (nframes > 0xFFFFFFFFull) return fail(TRM_EINVAL, "too many frames");
+    std::vector<float> f32(nframes * 16);
+    const double *src = reinterpret_cast<const double *>(frames);
+    for (size_t i = 0; i < nframes * 16; i++) f32[i] = (float)src[i];
+    size_t nout = trm_batch_samples_for_frames(t->b, nframes);
+    t->samples.assign(nout, 0.f);
+    uint64_t foff = 0, ooff = 0;
+    uint32_t nf = (uint32_t)nframes, ns = 0;
+    float mx = 0.f;
+    int rc = trm_batch_synthesize_host(t->b, 1, f32.data(), &foff, &nf, t->samples.data(), &ooff, &ns, &mx);
+    if (rc) { t->samples.clear(); return rc; }
+    t->numberSamples = ns;
+    t->maxSample = mx;
+    return TRM_OK;
+}
+
+size_t trm_tube_number_samples(const trm_tube *t) { return t ? t->numberSamples : 0; }
+double trm_tube_maximum_sample_value(const trm_tube *t) { return t ? (double)t->maxSample : 0.0; }
+const float *trm_tube_samples(const trm_tube *t) { return (t && !t->samples.empty()) ? t->samples.data() : nullptr; }
+
+int trm_tube_save_output_to_file(trm_tube *t, const char *filename)
+{
+    if (!t || !filename) return fail(TRM_EINVAL, "null argument");
+    // The reference prints these unconditionally (TRMTubeModel.m:372-376).
+    double scale = (32767.0 / (double)t->maxSample) * trm::io_amplitude(t->b->params.volume);
+    printf("\nnumber of samples:\t%-d\n", (int)t->numberSamples);
+    printf("maximum sample value:\t%.4f\n", (double)t->maxSample);
+    printf("scale:\t\t\t%.4f\n", scale);
+    int rc = trm::io_write_sound_file(filename, t->b->params, t->samples.data(), t->numberSamples, (double)t->maxSample);
+    if (rc) return fail(rc, "cannot write %s", filename);
+    return TRM_OK;
+}
+
+int trm_tube_generate_wav_data(trm_tube *t, uint8_t *buf, size_t cap, size_t *len)
+{
+    if (!t || !len) return fail(TRM_EINVAL, "null argument");
+    if (t->maxSample == 0.f) return fail(TRM_ESILENT, "maximumSampleValue == 0 (TRMTubeModel.m:511)");
+    size_t need = trm::io_wav_data_size(t->b->params, t->numberSamples);
+    *len = need;
+    if (!buf) return TRM_OK;
+    if (cap < need) return fail(TRM_EINVAL, "buffer too small: %zu < %zu", cap, need);
+    trm::io_wav_data(t->b->params, t->samples.data(), t->numberSamples, (double)t->maxSample, buf);
+    return TRM_OK;
+}
+
+// ------------------------------------------------------------------ TRMDataList
+int trm_data_list_read_file(const char *path, trm_input_params *params, trm_parameters **frames, size_t *nframes)
+{
+    if (!path || !params || !frames || !nframes) return fail(TRM_EINVAL, "null argument");
+    std::vector<trm_parameters> v;
+    int rc = trm::io_read_data_list(path, *params, v);
+    if (rc) return fail(rc, "%s: %s", path, trm_strerror(rc));
+    *nframes = v.size();
+    *frames = nullptr;
+    if (!v.empty()) {
+        *frames = (trm_parameters *)malloc(v.size() * sizeof(trm_parameters));
+        if (!*frames) return fail(TRM_ENOMEM, "frames");
+        memcpy(*frames, v.data(), v.size() * sizeof(trm_parameters));
+    }
+    return TRM_OK;
+}
+
+int trm_data_list_write_file(const char *path, const trm_input_params *params, const trm_parameters *frames, size_t nframes)
+{
+    if (!path || !params || (nframes && !frames)) return fail(TRM_EINVAL, "null argument");
+    int rc = trm::io_write_data_list(path, *params, frames, nframes);
+    if (rc) return fail(rc, "%s: %s", path, trm_strerror(rc));
+    return TRM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// trm_kernels.h -- launch interface between the C-ABI host code and trm_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "trm_lane.h"
+
+namespace trm {
+
+// Device pointers of one batch launch.  Layout in HBM:
+//   frames        fp32 [sum nframes][16], voice v owns rows frame_offset[v] .. +nframes[v]
+//   out           fp32 PCM at output rate, voice v's samples at out + out_offset[v]
+//   lp_noise      fp32 [>= max tube samples]: the voice-independent low-passed noise sequence
+//   src_rows      fp32 [65536][16]: converter coefficients per 16-bit phase (13 used)
+//   sine          fp32 [512]
+struct TubeArgs {
+    const float *frames;
+    const uint64_t *frame_offset;
+    const uint32_t *nframes;
+    float *out;
+    const uint64_t *out_offset;
+    uint32_t *number_samples;
+    float *max_sample;
+    const float *lp_noise;
+    const float *src_rows;
+    const float *sine;
+    uint32_t nvoices;
+};
+
+struct ScaleArgs {
+    const float *pcm;
+    const uint64_t *out_offset;
+    const uint32_t *number_samples;
+    const float *max_sample;
+    int16_t *pcm16;
+    double volumeAmp;     // amplitude(volume)
+    double balance;
+    int32_t channels;
+    int32_t forWavData;
+};
+
+hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
+// c = DEVICE pointer to the batch's trm::Const
+hipError_t launch_tube(const Const *c, const TubeArgs &a, hipStream_t stream);
+hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
+
+}  // namespace trm

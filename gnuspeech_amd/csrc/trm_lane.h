@@ -1,0 +1,408 @@
+// trm_lane.h -- the per-lane Tube Resonance Model: ONE tube voice per GPU lane.
+//
+// This is the arithmetic of -[TRMTubeModel synthesize]'s sample loop
+// (Frameworks/Tube/TRMTubeModel.m:292-354) re-designed for a 64-wide CDNA4 wavefront:
+//   * every lane owns one tube; all state lives in VGPRs (no per-lane tables);
+//   * everything that is identical for all voices of a batch (sample index, control-period
+//     position, sample-rate-converter phase, noise sequence, filter taps) is wave-uniform and
+//     lives in SGPRs / scalar loads;
+//   * fp32 for the signal path; fp64 only where the reference has a discontinuity
+//     (oscillator phase wrap, rint() of the glottal closure point, (int) of the frication
+//     position, dB clamps) -- SURVEY.md 9.4.
+//
+// The same header compiles for the device (HIP, gfx950) and, for numerics tests only, for the
+// host (tests/_emul).  No product path runs the host build.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIP__)
+#define TRM_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define TRM_HD inline
+#endif
+
+namespace trm {
+
+#ifndef TRM_WG_T
+#define TRM_WG_T float
+#endif
+typedef TRM_WG_T wg_t;   // waveguide state type (fp32 in the product; tests may widen it to study rounding)
+
+constexpr int kFirUnique = 25;      // 49 symmetric taps (TRMFIRFilter.h:7-9 design)
+constexpr int kFirTaps = 49;
+constexpr int kSrcWing = 13;        // ZERO_CROSSINGS (TRMSampleRateConverter.m:10)
+constexpr int kSrcWindow = 26;
+constexpr int kSrcRow = 16;         // coefficient row, 13 used + 3 pad (one s_load_dwordx16)
+constexpr int kTableLen = 512;      // TRMWavetable.m:22
+constexpr float kVtScale = 0.125f;  // TRMTubeModel.m:72
+
+// ---------------------------------------------------------------- math primitives
+#if defined(__HIP_DEVICE_COMPILE__)
+TRM_HD float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }       // v_rcp_f32, 1 ulp
+TRM_HD float exp2_f(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32, args here are in [-20, 0]
+TRM_HD float fma_f(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+TRM_HD double exp2_d(double x) { return exp2(x); }
+TRM_HD double rint_d(double x) { return __builtin_rint(x); }
+TRM_HD float rint_f(float x) { return __builtin_rintf(x); }
+#else
+TRM_HD float rcp_f(float x) { return 1.0f / x; }
+TRM_HD float exp2_f(float x) { return exp2f(x); }
+TRM_HD float fma_f(float a, float b, float c) { return fmaf(a, b, c); }
+TRM_HD double exp2_d(double x) { return exp2(x); }
+TRM_HD double rint_d(double x) { return rint(x); }
+TRM_HD float rint_f(float x) { return rintf(x); }
+#endif
+
+// sin / cos on [0, pi/4] (Taylor; truncation < 3e-8, below fp32 epsilon)
+TRM_HD float sin_q(float y)
+{
+    float y2 = y * y;
+    float p = fma_f(y2, 2.7557319e-6f, -1.9841270e-4f);
+    p = fma_f(y2, p, 8.3333333e-3f);
+    p = fma_f(y2, p, -1.6666667e-1f);
+    return fma_f(y * y2, p, y);
+}
+TRM_HD float cos_q(float y)
+{
+    float y2 = y * y;
+    float p = fma_f(y2, 2.4801587e-5f, -1.3888889e-3f);
+    p = fma_f(y2, p, 4.1666667e-2f);
+    p = fma_f(y2, p, -0.5f);
+    return fma_f(y2, p, 1.0f);
+}
+
+// ---------------------------------------------------------------- wave-uniform constants
+// Derived once per batch on the host from trm_input_params (TRMTubeModel.m:196-241).
+struct Const {
+    int32_t controlPeriod;
+    int32_t sampleRate;
+    int32_t waveform;           // 0 pulse, 1 sine
+    int32_t usesModulation;
+    float invControlPeriod;
+    float damping;              // 1 - loss/100                              (:216)
+    float breath;               // breathiness/100                           (:210)
+    float crossmixFactor;       // 1/amplitude(mixOffset)                    (:213)
+    float nasalK[5];            // NC2..NC6, fixed                           (:692-707)
+    float onePlusNK6;           // 1 + NC6, formed in double                 (:849)
+    float noseR1sq;             // noseRadius[1]^2, for NC1                  (:741)
+    float apScaleSq;            // apScale^2, for C8                         (:724)
+    float mA10, mB11, mA20, mA21, mB21;   // mouth reflection/radiation pair (TRMFilters.m:34-45)
+    float nA10, nB11, nA20, nA21, nB21;   // nose pair
+    float ta0, tb1, throatGain;           // throat low-pass                 (TRMFilters.m:64-68)
+    float invSampleRate;
+    // glottal pulse table geometry (TRMWavetable.m:71-75)
+    int32_t tableDiv1, tableDiv2;
+    float invDiv1;
+    double tnDelta;
+    double basicIncrement;      // 512 / sampleRate
+    double invControlPeriodD;
+    float fir[kFirUnique];      // c[0..24]; c[48-i] == c[i]
+    // sample-rate converter (TRMSampleRateConverter.m:80-98)
+    uint32_t timeRegisterIncrement;
+    uint32_t phaseIncrement;    // down-sampling only
+    int32_t padSize;
+    int32_t upsample;           // sampleRateRatio >= 1
+    float sampleRateRatio;      // for the down-sampling phase computation (double on host)
+    double sampleRateRatioD;
+};
+
+// Per-lane control-period interpolation state (TRMTubeModel.m:611-688).  Columns follow the
+// frame order of TRMDataList.m:223-233.
+struct Track {
+    // fp64: the three columns that feed quantisers / the phase accumulator
+    double f0, f0Ratio;         // 220*2^((pitch+3)/12) as a geometric sequence per sample
+    double glotDb, glotDbDelta; // dB value, repeated addition like the reference
+    double axGeo, axRatio;      // 10^((dB-60)/20) as a geometric sequence
+    double fricPos, fricPosDelta;
+    // fp32 direct interpolation base + delta: aspVol, fricVol, fricCF, fricBW, r1..r8, velum
+    float base[13], delta[13];
+};
+
+struct Lane {
+    // waveguide: travelling-wave values of the previous sample (TRMTubeModel.m:161-165)
+    wg_t oT[10], oB[10];        // oropharynx top / bottom
+    wg_t nT[6], nB[6];          // nasal
+    wg_t mReflY, mRadX, mRadY;  // mouth filter memories
+    wg_t nReflY, nRadX, nRadY;  // nose filter memories
+    wg_t throatY;
+    float bpX1, bpX2, bpY1, bpY2;   // frication band-pass memory (TRMFilters.m:19-29)
+    double oscPos;              // wavetable position (TRMWavetable.m:165-168)
+    float fir[24];              // transposed-form partial sums of the 49-tap FIR
+    float src[kSrcWindow];      // last 26 tube-rate samples, src[25] newest
+    float maxAbs;
+};
+
+TRM_HD void lane_reset(Lane &L)
+{
+    for (int i = 0; i < 10; i++) { L.oT[i] = 0.f; L.oB[i] = 0.f; }
+    for (int i = 0; i < 6; i++) { L.nT[i] = 0.f; L.nB[i] = 0.f; }
+    L.mReflY = L.mRadX = L.mRadY = 0.f;
+    L.nReflY = L.nRadX = L.nRadY = 0.f;
+    L.throatY = 0.f;
+    L.bpX1 = L.bpX2 = L.bpY1 = L.bpY2 = 0.f;
+    L.oscPos = 0.0;
+    for (int i = 0; i < 24; i++) L.fir[i] = 0.f;
+    for (int i = 0; i < kSrcWindow; i++) L.src[i] = 0.f;
+    L.maxAbs = 0.f;
+}
+
+// -setControlRateParameters:previous: (TRMTubeModel.m:611-672).  prev/cur = 16 fp32 frame values.
+TRM_HD void track_setup(Track &T, const Const &C, const float *prev, const float *cur)
+{
+    const double kLog2_10_over_20 = 0.16609640474436813;   // log2(10)/20
+    double p0 = (double)prev[0], dp = ((double)cur[0] - p0) * C.invControlPeriodD;
+    T.f0 = 220.0 * exp2_d((p0 + 3.0) * (1.0 / 12.0));      // frequency(), TRMUtility.m:44-47
+    T.f0Ratio = exp2_d(dp * (1.0 / 12.0));
+    double v0 = (double)prev[1], dv = ((double)cur[1] - v0) / (double)C.controlPeriod;
+    T.glotDb = v0;
+    T.glotDbDelta = dv;
+    T.axGeo = exp2_d((v0 - 60.0) * kLog2_10_over_20);      // amplitude(), TRMUtility.m:26-41
+    T.axRatio = exp2_d(dv * kLog2_10_over_20);
+    T.fricPos = (double)prev[4];
+    T.fricPosDelta = ((double)cur[4] - T.fricPos) / (double)C.controlPeriod;
+    const int col[13] = {2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    for (int i = 0; i < 13; i++) {
+        T.base[i] = prev[col[i]];
+        T.delta[i] = (cur[col[i]] - prev[col[i]]) * C.invControlPeriod;
+    }
+}
+
+// dB -> linear amplitude with the reference's clamps (TRMUtility.m:26-41), fp32.
+TRM_HD float amplitude_f(float db)
+{
+    float a = exp2_f((db - 60.0f) * 0.16609640474f);
+    a = db >= 60.0f ? 1.0f : a;
+    return db <= 0.0f ? 0.0f : a;
+}
+
+// One entry of the glottal pulse table as a pure function of the closure point
+// (TRMWavetable.m:79-96 rise/closed, :117-156 fall rewritten from the amplitude).
+TRM_HD float pulse_table(int i, const Const &C, int newDiv2, float invFall)
+{
+    float x = (float)i * C.invDiv1;
+    float rise = x * x * fma_f(-2.0f, x, 3.0f);
+    float xf = (float)(i - C.tableDiv1) * invFall;
+    float fall = fma_f(-xf, xf, 1.0f);
+    float v = i < newDiv2 ? fall : 0.0f;
+    return i < C.tableDiv1 ? rise : v;
+}
+
+// The per-sample update.  `j` = position in the control period (uniform), `lpNoise` = the
+// voice-independent low-passed noise sample (uniform), `sineTab` = 512-entry sine table or null.
+// Returns the tube-rate output sample (what the reference hands to -dataFill:, :346).
+template <class SineLookup>
+TRM_HD float lane_sample(Lane &L, Track &T, const Const &C, int j, float lpNoise, SineLookup sineTab)
+{
+    const float fj = (float)j;
+    // ---- control-rate interpolation, fp32 columns (:676-688 evaluated as base + j*delta)
+    float aspDb = fma_f(fj, T.delta[0], T.base[0]);
+    float fricDb = fma_f(fj, T.delta[1], T.base[1]);
+    float fricCF = fma_f(fj, T.delta[2], T.base[2]);
+    float fricBW = fma_f(fj, T.delta[3], T.base[3]);
+    float r[8];
+    for (int i = 0; i < 8; i++) r[i] = fma_f(fj, T.delta[4 + i], T.base[4 + i]);
+    float velum = fma_f(fj, T.delta[12], T.base[12]);
+
+    // ---- fp64 columns: amplitude of voicing with its clamps, closure point, pitch (:294-296)
+    double axd = T.glotDb >= 60.0 ? 1.0 : T.axGeo;
+    axd = T.glotDb <= 0.0 ? 0.0 : axd;
+    const float ax = (float)axd;
+    const float ah1 = amplitude_f(aspDb);
+
+    // ---- scattering coefficients (:712-744)
+    float r2[8];
+    for (int i = 0; i < 8; i++) r2[i] = r[i] * r[i];
+    float k[8];
+    for (int i = 0; i < 7; i++) k[i] = (r2[i] - r2[i + 1]) * rcp_f(r2[i] + r2[i + 1]);
+    float rk8 = rcp_f(r2[7] + C.apScaleSq);
+    k[7] = (r2[7] - C.apScaleSq) * rk8;
+    float onePlusK8 = (r2[7] + r2[7]) * rk8;     // 1 + C8 without the cancellation of a nearly closed mouth
+    float v2 = velum * velum;
+    float jsum = 2.0f * rcp_f(r2[3] + r2[3] + v2);
+    float alphaLR = jsum * r2[3];
+    float alphaU = jsum * v2;
+    float nk1 = (v2 - C.noseR1sq) * rcp_f(v2 + C.noseR1sq);
+
+    // ---- frication taps (:748-773)
+    float fricAmp = amplitude_f(fricDb);
+    int ip = (int)T.fricPos;
+    float comp = (float)(T.fricPos - (double)ip);
+    float tapA = (1.0f - comp) * fricAmp;       // tap[ip]
+    float tapB = comp * fricAmp;                // tap[ip+1] when ip+1 < 8
+    float tap[8];
+    tap[0] = ip == 0 ? tapA : 0.0f;
+    for (int i = 1; i < 8; i++) {
+        float t = i == ip ? tapA : 0.0f;
+        tap[i] = i - 1 == ip ? tapB : t;
+    }
+
+    // ---- band-pass coefficients (TRMFilters.m:9-17): tan(pi*BW/SR), cos(2*pi*CF/SR)
+    float bpBeta, bpGamma, bpAlpha;
+    {
+        float v = fricBW * C.invSampleRate;
+        v = v - rint_f(v);                      // tan has period 1 in v
+        float a = fabsf(v);
+        bool hi = a > 0.25f;
+        float y = 3.14159265358979f * (hi ? 0.5f - a : a);
+        float s = sin_q(y), c = cos_q(y);
+        float num = hi ? c : s, den = hi ? s : c;     // tan = num/den
+        num = v < 0.0f ? -num : num;
+        bpBeta = (den - num) * rcp_f(2.0f * (den + num));   // (1-t)/(2(1+t))
+        float u = fricCF * C.invSampleRate;
+        u = fabsf(u - rint_f(u));               // [0, .5]
+        bool neg = u > 0.25f;
+        u = neg ? 0.5f - u : u;                 // [0, .25]: angle in [0, pi/2]
+        bool swap = u > 0.125f;
+        float yy = 6.28318530717959f * (swap ? 0.25f - u : u);
+        float cv = swap ? sin_q(yy) : cos_q(yy);
+        cv = neg ? -cv : cv;
+        bpGamma = (0.5f + bpBeta) * cv;
+        bpAlpha = (0.5f - bpBeta) * 0.5f;
+    }
+
+    // ---- glottal source: 2x oversampled wavetable oscillator + 49-tap FIR (TRMWavetable.m:117-195)
+    float wa, wb;   // the two oversampled table reads of this sample
+    {
+        double inc = (T.f0 * 0.5) * C.basicIncrement;
+        double pos1 = L.oscPos + inc;
+        pos1 = pos1 > 511.0 ? pos1 - 512.0 : pos1;          // mod0(), :28-34
+        double pos2 = pos1 + inc;
+        pos2 = pos2 > 511.0 ? pos2 - 512.0 : pos2;
+        L.oscPos = pos2;
+        int lo1 = (int)pos1, lo2 = (int)pos2;
+        float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
+        int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
+        int up2 = lo2 + 1 > 511 ? lo2 + 1 - 512 : lo2 + 1;
+        float a0, a1, b0, b1;
+        if (C.waveform == 0) {
+            int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
+            float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
+            a0 = pulse_table(lo1, C, newDiv2, invFall);
+            a1 = pulse_table(up1, C, newDiv2, invFall);
+            b0 = pulse_table(lo2, C, newDiv2, invFall);
+            b1 = pulse_table(up2, C, newDiv2, invFall);
+        } else {
+            a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
+        }
+        wa = fma_f(fr1, a1 - a0, a0);
+        wb = fma_f(fr2, b1 - b0, b0);
+    }
+    // FIR in transposed form: y[m] = sum c[2k] b[m-k] + c[2k+1] a[m-k]  (TRMFIRFilter.m:116-146)
+    float pulse;
+    {
+        auto c = [&](int i) { return C.fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };
+        pulse = fma_f(c(0), wb, fma_f(c(1), wa, L.fir[0]));
+        for (int q = 0; q < 23; q++) L.fir[q] = fma_f(c(2 * q + 2), wb, fma_f(c(2 * q + 3), wa, L.fir[q + 1]));
+        L.fir[23] = c(48) * wb;
+    }
+
+    // ---- source mixing (:315-333)
+    float pulsedNoise = lpNoise * pulse;
+    pulse = ax * fma_f(pulsedNoise, C.breath, pulse * (1.0f - C.breath));
+    float sig;
+    if (C.usesModulation) {
+        float cm = ax * C.crossmixFactor;
+        cm = cm < 1.0f ? cm : 1.0f;
+        sig = fma_f(pulsedNoise, cm, lpNoise * (1.0f - cm));
+    } else
+        sig = lpNoise;
+
+    // ---- frication band-pass (TRMFilters.m:19-29), evaluated before the tract (:336-337)
+    float fric = 2.0f * fma_f(bpAlpha, sig - L.bpX2, fma_f(bpGamma, L.bpY1, -(bpBeta * L.bpY2)));
+    L.bpX2 = L.bpX1; L.bpX1 = sig; L.bpY2 = L.bpY1; L.bpY1 = fric;
+
+    // ---- waveguide (:778-853): all new values from old values only
+    const wg_t d = C.damping;
+    const wg_t input = fma_f(ah1, sig, pulse) * kVtScale;
+    const wg_t fr = fric;
+    wg_t nOT[10], nOB[10], nNT[6], nNB[6];
+    nOT[0] = L.oB[0] * d + input;
+    {
+        wg_t dl = k[0] * (L.oT[0] - L.oB[1]);
+        nOT[1] = (L.oT[0] + dl) * d;
+        nOB[0] = (L.oB[1] + dl) * d;
+    }
+    for (int i = 1; i < 3; i++) {             // S2-S3, S3-S4 with taps FC1, FC2
+        wg_t dl = k[i] * (L.oT[i] - L.oB[i + 1]);
+        nOT[i + 1] = (L.oT[i] + dl) * d + tap[i - 1] * fr;
+        nOB[i] = (L.oB[i + 1] + dl) * d;
+    }
+    {
+        wg_t jp = alphaLR * L.oT[3] + (alphaLR * L.oB[4] + alphaU * L.nB[0]);
+        nOB[3] = (jp - L.oT[3]) * d;
+        nOT[4] = (jp - L.oB[4]) * d + tap[2] * fr;
+        nNT[0] = (jp - L.nB[0]) * d;
+    }
+    {
+        wg_t dl = k[3] * (L.oT[4] - L.oB[5]);
+        nOT[5] = (L.oT[4] + dl) * d + tap[3] * fr;
+        nOB[4] = (L.oB[5] + dl) * d;
+    }
+    nOT[6] = L.oT[5] * d + tap[4] * fr;
+    nOB[5] = L.oB[6] * d;
+    for (int i = 6; i < 9; i++) {             // S7-S8, S8-S9, S9-S10 with taps FC6..FC8
+        wg_t dl = k[i - 2] * (L.oT[i] - L.oB[i + 1]);
+        nOT[i + 1] = (L.oT[i] + dl) * d + tap[i - 1] * fr;
+        nOB[i] = (L.oB[i + 1] + dl) * d;
+    }
+    wg_t out;
+    {
+        wg_t refl = C.mA10 * (k[7] * L.oT[9]) - C.mB11 * L.mReflY;              // TRMFilters.m:47-52
+        L.mReflY = refl;
+        nOB[9] = d * refl;
+        wg_t rin = onePlusK8 * L.oT[9];
+        wg_t rad = C.mA20 * rin + (C.mA21 * L.mRadX - C.mB21 * L.mRadY);        // :54-60
+        L.mRadX = rin; L.mRadY = rad;
+        out = rad;
+    }
+    {
+        float kk[5] = {nk1, C.nasalK[0], C.nasalK[1], C.nasalK[2], C.nasalK[3]};
+        for (int i = 0; i < 5; i++) {
+            wg_t dl = kk[i] * (L.nT[i] - L.nB[i + 1]);
+            nNT[i + 1] = (L.nT[i] + dl) * d;
+            nNB[i] = (L.nB[i + 1] + dl) * d;
+        }
+        wg_t refl = C.nA10 * (C.nasalK[4] * L.nT[5]) - C.nB11 * L.nReflY;
+        L.nReflY = refl;
+        nNB[5] = d * refl;
+        wg_t rin = C.onePlusNK6 * L.nT[5];
+        wg_t rad = C.nA20 * rin + (C.nA21 * L.nRadX - C.nB21 * L.nRadY);
+        L.nRadX = rin; L.nRadY = rad;
+        out += rad;
+    }
+    for (int i = 0; i < 10; i++) { L.oT[i] = nOT[i]; L.oB[i] = nOB[i]; }
+    for (int i = 0; i < 6; i++) { L.nT[i] = nNT[i]; L.nB[i] = nNB[i]; }
+
+    // ---- throat (:341, TRMFilters.m:72-77)
+    wg_t ty = C.ta0 * (pulse * kVtScale) + C.tb1 * L.throatY;
+    L.throatY = ty;
+    out = ty * C.throatGain + out;
+
+    // ---- advance the fp64 tracks (:351)
+    T.glotDb += T.glotDbDelta;
+    T.axGeo *= T.axRatio;
+    T.f0 *= T.f0Ratio;
+    T.fricPos += T.fricPosDelta;
+    return (float)out;
+}
+
+// Push one tube-rate sample into the converter window (TRMRingBuffer.m:47-60, window form).
+TRM_HD void src_push(Lane &L, float s)
+{
+    for (int i = 0; i < kSrcWindow - 1; i++) L.src[i] = L.src[i + 1];
+    L.src[kSrcWindow - 1] = s;
+}
+
+// One up-sampled output (TRMSampleRateConverter.m:171-233): 13 left + 13 right taps.
+// cl/cr = coefficient rows for the left wing (phase f) and right wing (phase ~f).
+TRM_HD float src_emit_up(const Lane &L, const float *cl, const float *cr)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < kSrcWing; i++) acc = fma_f(L.src[12 - i], cl[i], acc);
+    for (int i = 0; i < kSrcWing; i++) acc = fma_f(L.src[13 + i], cr[i], acc);
+    return acc;
+}
+
+}  // namespace trm

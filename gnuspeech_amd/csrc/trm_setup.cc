@@ -1,0 +1,253 @@
+// trm_setup.cc -- see trm_setup.h.  Host-side, once per tube/batch; double precision.
+#include "trm_setup.h"
+
+#include <math.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace trm {
+
+namespace {
+
+constexpr int kLimit = 200;            // COEFFICIENT_LIMIT, TRMFIRFilter.m:13
+constexpr int kSrcLen = 13 * 256;      // FILTER_LENGTH, TRMSampleRateConverter.m:20
+
+double amplitude(double db)            // TRMUtility.m:26-41
+{
+    db -= 60.0;
+    if (db <= -60.0) return 0.0;
+    if (db >= 0.0) return 1.0;
+    return pow(10.0, db / 20.0);
+}
+
+double izero(double x)                 // TRMUtility.m:50-66
+{
+    double sum = 1, u = 1, n = 1, halfx = x / 2.0;
+    do {
+        double t = halfx / n;
+        n += 1;
+        t *= t;
+        u *= t;
+        sum += u;
+    } while (u >= 1E-21 * sum);
+    return sum;
+}
+
+// Best rational approximation with bounded denominator (TRMFIRFilter.m:265-310).
+void rational(double number, int &order, int &num, int &den)
+{
+    if (order <= 0) { num = den = 0; order = -1; return; }
+    double frac = fabs(number - (int)number);
+    int omax = 2 * order > kLimit ? kLimit : 2 * order;
+    int modulus = 0;
+    double best = 1.0;
+    for (int i = order; i <= omax; i++) {
+        double ps = i * frac;
+        int ip = (int)(ps + 0.5);
+        double e = fabs((ps - ip) / i);
+        if (e < best) { best = e; modulus = ip; den = i; }
+    }
+    num = (int)fabs(number) * den + modulus;
+    if (number < 0) num = -num;
+    order = den - 1;
+    if (num == den) { den = omax; order = num = den - 1; }
+}
+
+}  // namespace
+
+// Maximally-flat linear-phase low-pass design (TRMFIRFilter.m:161-233), then trim (:236-244)
+// and mirror into taps (:73-83).
+int design_fir(double beta, double gamma, double cutoff, std::vector<double> &taps)
+{
+    taps.clear();
+    if (beta <= 0.0 || beta >= 0.5) return -1;
+    double bmin = 2.0 * beta < 1.0 - 2.0 * beta ? 2.0 * beta : 1.0 - 2.0 * beta;
+    if (gamma <= 0.0 || gamma >= bmin) return -2;
+    int nt = (int)(1.0 / (4.0 * gamma * gamma));
+    if (nt > 160) return -3;
+    double ac = (1.0 + cos(2.0 * M_PI * beta)) / 2.0;
+    int numer = 0, np = 0;
+    rational(ac, nt, numer, np);
+    int n = 2 * np - 1;
+    if (numer == 0) numer = 1;
+    std::vector<double> a(kLimit + 2, 0.0), c(kLimit + 2, 0.0), coef(kLimit + 2, 0.0);
+    c[1] = a[1] = 1.0;
+    int ll = nt - numer;
+    for (int i = 2; i <= np; i++) {
+        double sum = 1.0;
+        c[i] = cos(2.0 * M_PI * ((double)(i - 1) / (double)n));
+        double x = (1.0 - c[i]) / 2.0, y = x;
+        if (numer == nt) continue;
+        for (int j = 1; j <= ll; j++) {
+            double z = y;
+            if (numer != 1)
+                for (int jj = 1; jj <= numer - 1; jj++) z *= 1.0 + (double)j / (double)jj;
+            y *= x;
+            sum += z;
+        }
+        a[i] = sum * pow(1.0 - x, numer);
+    }
+    for (int i = 1; i <= np; i++) {
+        coef[i] = a[1] / 2.0;
+        for (int j = 2; j <= np; j++) {
+            int m = ((i - 1) * (j - 1)) % n;
+            if (m > nt) m = n - m;
+            coef[i] += c[m + 1] * a[j];
+        }
+        coef[i] *= 2.0 / (double)n;
+    }
+    int ncoef = np;
+    for (int i = np; i > 0; i--)
+        if (fabs(coef[i]) >= fabs(cutoff)) { ncoef = i; break; }
+    int ntaps = 2 * ncoef - 1;
+    taps.resize(ntaps);
+    int inc = -1, ptr = ncoef;
+    for (int i = 0; i < ntaps; i++) {
+        taps[i] = coef[ptr];
+        ptr += inc;
+        if (ptr <= 0) { ptr = 2; inc = 1; }
+    }
+    return ntaps;
+}
+
+void build_src_h(std::vector<double> &h, std::vector<double> &dh)
+{
+    h.assign(kSrcLen, 0.0);
+    dh.assign(kSrcLen, 0.0);
+    const double lp = 11.0 / 13.0, kaiser = 5.658;
+    h[0] = lp;
+    double x = M_PI / 256.0;
+    for (int i = 1; i < kSrcLen; i++) {
+        double y = (double)i * x;
+        h[i] = sin(y * lp) / y;
+    }
+    double ib = 1.0 / izero(kaiser);
+    for (int i = 0; i < kSrcLen; i++) {
+        double t = (double)i / kSrcLen;
+        h[i] *= izero(kaiser * sqrt(1.0 - t * t)) * ib;
+    }
+    for (int i = 0; i < kSrcLen - 1; i++) dh[i] = h[i + 1] - h[i];
+    dh[kSrcLen - 1] = 0.0 - h[kSrcLen - 1];
+}
+
+void build_src_rows(std::vector<float> &rows)
+{
+    std::vector<double> h, dh;
+    build_src_h(h, dh);
+    rows.assign((size_t)65536 * kSrcRow, 0.0f);
+    for (uint32_t f = 0; f < 65536; f++) {
+        uint32_t l = f >> 8, m = f & 255;
+        double interp = (double)m / 256.0;
+        for (int i = 0; i < kSrcWing; i++) {
+            uint32_t fi = l + 256u * i;
+            rows[(size_t)f * kSrcRow + i] = (float)(h[fi] + dh[fi] * interp);
+        }
+    }
+}
+
+void build_src_fine(std::vector<float> &fine)
+{
+    std::vector<double> h, dh;
+    build_src_h(h, dh);
+    fine.resize((size_t)kSrcLen * 256);
+    for (uint32_t q = 0; q < (uint32_t)kSrcLen * 256u; q++)
+        fine[q] = (float)(h[q >> 8] + dh[q >> 8] * ((double)(q & 255) / 256.0));
+}
+
+void build_sine_table(std::vector<float> &tab)
+{
+    tab.resize(kTableLen);
+    for (int i = 0; i < kTableLen; i++) tab[i] = (float)sin(((double)i / (double)kTableLen) * 2.0 * M_PI);
+}
+
+uint64_t count_outputs(const trm_derived &d, uint64_t ntube)
+{
+    // output k sits at input time k*inc (16.16); it is produced while floor(k*inc/65536) <
+    // ntube + 2*pad (TRMSampleRateConverter.m:160-173 with the 2*pad zero flush, TRMRingBuffer.m:85-93)
+    uint64_t total = ntube + 2ull * (uint64_t)d.padSize;
+    uint64_t inc = d.timeRegisterIncrement;
+    return (total * 65536ull + inc - 1) / inc;
+}
+
+int build_const(const trm_input_params &p, Const &c, trm_derived &d)
+{
+    memset(&c, 0, sizeof c);
+    memset(&d, 0, sizeof d);
+    if (!(p.length > 0.0)) return TRM_EINVAL_LENGTH;                      // TRMTubeModel.m:197,204-207
+    double speed = 331.4 + 0.6 * p.temperature;                          // TRMUtility.m:20-23
+    d.controlPeriod = (int32_t)rint((speed * 10 * 100.0) / (p.length * p.controlRate));   // :200
+    d.sampleRate = (int32_t)(p.controlRate * d.controlPeriod);           // :201 (float arithmetic)
+    if (d.controlPeriod < 1 || d.sampleRate < 1) return TRM_ERANGE;
+    d.actualTubeLength = (speed * 10 * 100.0) / d.sampleRate;            // :202
+    double nyquist = (double)d.sampleRate / 2.0;
+    d.sampleRateRatio = (double)p.outputRate / (double)d.sampleRate;     // TRMSampleRateConverter.m:80
+    if (!(d.sampleRateRatio > 0.0)) return TRM_ERANGE;
+    d.timeRegisterIncrement = (uint32_t)(int)rint(65536.0 / d.sampleRateRatio);            // :83
+    if (d.timeRegisterIncrement == 0) return TRM_ERANGE;
+    double rounded = 65536.0 / (double)d.timeRegisterIncrement;          // :86
+    if (d.sampleRateRatio >= 1.0) {
+        d.phaseIncrement = 0;
+        d.padSize = 13;
+    } else {
+        d.phaseIncrement = (uint32_t)rint(d.sampleRateRatio * 65536.0);  // :92
+        d.padSize = (int32_t)((float)13 / rounded) + 1;                  // :96
+    }
+    std::vector<double> taps;
+    int nt = design_fir(0.2, 0.1, 0.00000001, taps);                     // TRMFIRFilter.h:7-9
+    if (nt != kFirTaps) return TRM_EFIR;
+    d.firTaps = nt;
+
+    c.controlPeriod = d.controlPeriod;
+    c.sampleRate = d.sampleRate;
+    c.waveform = p.waveform == TRM_WAVEFORM_PULSE ? 0 : 1;
+    c.usesModulation = p.usesModulation != 0;
+    c.invControlPeriod = (float)(1.0 / d.controlPeriod);
+    c.invControlPeriodD = 1.0 / d.controlPeriod;
+    c.damping = (float)(1.0 - p.lossFactor / 100.0);                     // :216
+    c.breath = (float)(p.breathiness / 100.0);                           // :210
+    c.crossmixFactor = (float)(1.0 / amplitude(p.mixOffset));            // :213
+    for (int i = 1; i < 5; i++) {                                        // :695-699
+        double a2 = p.noseRadius[i] * p.noseRadius[i], b2 = p.noseRadius[i + 1] * p.noseRadius[i + 1];
+        c.nasalK[i - 1] = (float)((a2 - b2) / (a2 + b2));
+    }
+    {
+        double a2 = p.noseRadius[5] * p.noseRadius[5], b2 = p.apScale * p.apScale;   // :703-705
+        c.nasalK[4] = (float)((a2 - b2) / (a2 + b2));
+        c.onePlusNK6 = (float)(1.0 + (a2 - b2) / (a2 + b2));
+    }
+    c.noseR1sq = (float)(p.noseRadius[1] * p.noseRadius[1]);
+    c.apScaleSq = (float)(p.apScale * p.apScale);
+    {
+        double coeff = (nyquist - p.mouthCoef) / nyquist;                // :222, TRMFilters.m:34-45
+        c.mB11 = (float)-coeff; c.mA10 = (float)(1.0 - fabs(-coeff));
+        c.mA20 = (float)coeff; c.mA21 = c.mB21 = (float)-coeff;
+        coeff = (nyquist - p.noseCoef) / nyquist;                        // :225
+        c.nB11 = (float)-coeff; c.nA10 = (float)(1.0 - fabs(-coeff));
+        c.nA20 = (float)coeff; c.nA21 = c.nB21 = (float)-coeff;
+    }
+    {
+        double ta0 = (p.throatCutoff * 2.0) / d.sampleRate;              // :238
+        c.ta0 = (float)ta0; c.tb1 = (float)(1.0 - ta0);
+        c.throatGain = (float)amplitude(p.throatVol);                    // :239
+    }
+    c.invSampleRate = (float)(1.0 / d.sampleRate);
+    c.tableDiv1 = (int32_t)rint(512 * (p.tp / 100.0));                   // TRMWavetable.m:71-75
+    c.tableDiv2 = (int32_t)rint(512 * ((p.tp + p.tnMax) / 100.0));
+    c.invDiv1 = c.tableDiv1 > 0 ? (float)(1.0 / c.tableDiv1) : 0.0f;
+    c.tnDelta = rint(512 * ((p.tnMax - p.tnMin) / 100.0));
+    c.basicIncrement = 512.0 / (double)d.sampleRate;
+    for (int i = 0; i < kFirUnique; i++) c.fir[i] = (float)taps[i];
+    c.timeRegisterIncrement = d.timeRegisterIncrement;
+    c.phaseIncrement = d.phaseIncrement;
+    c.padSize = d.padSize;
+    c.upsample = d.sampleRateRatio >= 1.0;
+    c.sampleRateRatio = (float)d.sampleRateRatio;
+    c.sampleRateRatioD = d.sampleRateRatio;
+    if (c.tableDiv1 < 0 || c.tableDiv2 > 512 || c.tableDiv1 > c.tableDiv2) return TRM_ERANGE;
+    return TRM_OK;
+}
+
+}  // namespace trm

@@ -1,0 +1,41 @@
+// trm_setup.h -- host-side derivation of everything -[TRMTubeModel initWithInputData:] computes
+// once per tube (Frameworks/Tube/TRMTubeModel.m:186-260) into the wave-uniform trm::Const,
+// plus the sample-rate-converter coefficient tables and the exact output-count bookkeeping.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/trm_c_api.h"
+#include "trm_lane.h"
+
+namespace trm {
+
+// TRM_OK or TRM_EINVAL_LENGTH / TRM_EFIR / TRM_ERANGE.
+int build_const(const trm_input_params &p, Const &c, trm_derived &d);
+
+// 49-tap oscillator FIR (TRMFIRFilter.m:37-98,161-310).  Returns tap count (<0 on failure).
+int design_fir(double beta, double gamma, double cutoff, std::vector<double> &taps);
+
+// h[] / deltaH[] of the converter (TRMSampleRateConverter.m:110-131), 3328 doubles each.
+void build_src_h(std::vector<double> &h, std::vector<double> &dh);
+
+// Up-sampling coefficient rows: row[f][i] = h[l+256i] + deltaH[l+256i]*m/256 for the 16-bit
+// phase f = (l<<8)|m, i < 13 (TRMSampleRateConverter.m:182-203); 65536 x kSrcRow floats.
+void build_src_rows(std::vector<float> &rows);
+
+// Fine table for the down-sampling branch: fine[q] = h[q>>8] + deltaH[q>>8]*(q&255)/256,
+// q < 3328*256 (TRMSampleRateConverter.m:246-270).
+void build_src_fine(std::vector<float> &fine);
+
+// Exact number of converter outputs for a tube that received `ntube` samples, following the
+// ring-buffer bookkeeping literally (TRMRingBuffer.m:47-93, TRMSampleRateConverter.m:155-298),
+// integer arithmetic only.
+uint64_t count_outputs(const trm_derived &d, uint64_t ntube);
+
+// 512-entry sine table (TRMWavetable.m:98-101), fp32.
+void build_sine_table(std::vector<float> &tab);
+
+}  // namespace trm

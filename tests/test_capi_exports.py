@@ -1,0 +1,68 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol
+include/trm_c_api.h declares; the text format parser/writer round-trips.  No GPU compute here."""
+import os
+import re
+
+import numpy as np
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gnuspeech_amd
+    L = gnuspeech_amd.lib()
+    hdr = open(os.path.join(ROOT, "include", "trm_c_api.h")).read()
+    declared = set(re.findall(r"\b(trm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(gnuspeech_amd._capi.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.trm_build_info()
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    import gnuspeech_amd
+    out = subprocess.run(["nm", "-D", gnuspeech_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "trm_oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "gnuspeech_amd")):
+        for f in files:
+            if f.endswith((".py", ".cc", ".h", ".hip")):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r"#include[^\n]*oracle|import[^\n]*oracle|oracle_lib|libtrm_oracle|trm_oracle_", txt), f
+
+
+def test_data_list_reads_reference_sample(tmp_path):
+    import gnuspeech_amd as g
+    dl = g.TRMDataList.initWithContentsOfFile(cases.GNUSPEECH_INPUT)
+    p = dl.inputParameters
+    assert len(dl.values) == 344                                   # 343 rows + doubled last (TRMDataList.m:239-241)
+    assert (p.outputRate, p.controlRate, p.channels, p.waveform, p.tp, p.tnMin, p.tnMax) == (22050.0, 250.0, 1, 0, 40.0, 16.0, 32.0)
+    assert list(p.noseRadius) == [0.0, 1.35, 1.96, 1.91, 1.3, 0.73] and p.usesModulation == 1 and p.mixOffset == 54.0
+    assert dl.values[0].valuesString == "-12.000 0.000 0.000 0.000 5.500 2500.000 500.000 0.800 0.890 0.990 0.810 0.760 1.050 1.230 0.010 0.100"
+    assert np.array_equal(dl.frame_array()[:-1], cases.load_gnuspeech_rows())
+    # writer -> parser round trip (MMSynthesisParameters.m:278-310 + TRMParameters.m:26-43 format)
+    out = tmp_path / "rt.trm"
+    dl.values = dl.values[:-1]
+    dl.writeToFile(out)
+    dl2 = g.TRMDataList.initWithContentsOfFile(out)
+    assert len(dl2.values) == 344 and np.array_equal(dl2.frame_array()[:-1], cases.load_gnuspeech_rows())
+    assert bytes(dl2.inputParameters.c) == bytes(p.c)
+    assert g.TRMDataList.initWithContentsOfFile(tmp_path / "missing.trm") is None
+    short = tmp_path / "short.trm"
+    short.write_text("0\n22050\n250\n")
+    assert g.TRMDataList.initWithContentsOfFile(short) is None     # truncated header -> nil
+
+
+def test_product_fails_loudly_without_gpu():
+    """On a box without a GPU every synthesis entry point errors out; nothing falls back to the CPU."""
+    import pytest
+    import gnuspeech_amd as g
+    if g.lib().trm_device_count() > 0:
+        pytest.skip("GPU present")
+    dl = g.TRMDataList()
+    dl.inputParameters = g.TRMInputParameters.from_dict(cases.monet_default_params())
+    with pytest.raises(g.TrmError) as ei:
+        g.TRMTubeModel.initWithInputData(dl)
+    assert ei.value.code == 6                                      # TRM_ENODEVICE
