@@ -50,7 +50,7 @@ EXPORTS = [
     "trm_tube_save_output_to_file", "trm_tube_generate_wav_data",
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
-    "trm_batch_kernel_time_ms", "trm_device_count", "trm_build_info",
+    "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info",
 ]
 
 _lib = None
@@ -69,6 +69,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C gnuspeech_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    # torch (the owner of device buffers / streams in this package) bundles its own HIP runtime under
+    # the same SONAME as /opt/rocm's.  Whichever is loaded first serves the whole process, and torch
+    # cannot run on the system copy: so when torch is installed, let it load its runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.trm_strerror.argtypes = [C.c_int]
@@ -101,6 +108,7 @@ def lib():
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]
     L.trm_batch_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.trm_batch_noise_table.argtypes = [vp, vp, C.c_size_t]
     for name in EXPORTS:
         getattr(L, name)
     _lib = L

@@ -110,6 +110,11 @@ class TRMBatch:
             st["max_sample"].data_ptr(), pcm16.data_ptr(), int(for_wav_data), C.c_void_p(s.cuda_stream)))
         return pcm16
 
+    def noise_table(self, n):
+        out = np.zeros(int(n), dtype=np.float32)
+        check(lib().trm_batch_noise_table(self._h, out.ctypes.data, int(n)))
+        return out
+
     def kernel_time_ms(self):
         t = C.c_double()
         n = C.c_uint32()

@@ -286,6 +286,18 @@ int trm_batch_kernel_time_ms(trm_batch *b, double *total_ms, uint32_t *launches)
     return TRM_OK;
 }
 
+int trm_batch_noise_table(trm_batch *b, float *host_out, size_t n)
+{
+    if (!b || !host_out) return fail(TRM_EINVAL, "null argument");
+    if (n > 0x7FFFFFF0ull) return fail(TRM_ERANGE, "too long");
+    HIP_TRY(hipSetDevice(b->device));
+    int rc = ensure_noise(b, (uint32_t)n, b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host_out, b->dNoise.p, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return TRM_OK;
+}
+
 int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames, const uint64_t *frame_offset,
                               const uint32_t *nframes, float *out, const uint64_t *out_offset,
                               uint32_t *number_samples, float *max_sample)

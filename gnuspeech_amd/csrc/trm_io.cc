@@ -107,6 +107,9 @@ int io_write_data_list(const char *path, const trm_input_params &p, const trm_pa
 }
 
 // ---------------------------------------------------------------- output scaling + containers
+// out-of-range values wrap modulo 2^16 like the reference's x86 build (stereo file path over-drives by up to 2x)
+static inline int16_t wrap16(double v) { return (int16_t)(uint16_t)(int64_t)v; }
+
 void io_scale_int16(const trm_input_params &p, const float *s, size_t n, double maxSample, bool forWavData, int16_t *out)
 {
     double scale = (32767.0 / maxSample) * io_amplitude(p.volume);      // TRMTubeModel.m:370,515
@@ -115,11 +118,11 @@ void io_scale_int16(const trm_input_params &p, const float *s, size_t n, double 
         double left = -((p.balance / 2.0) - 0.5) * scale * g;
         double right = ((p.balance / 2.0) + 0.5) * scale * g;
         for (size_t i = 0; i < n; i++) {
-            out[2 * i] = (int16_t)rint((double)s[i] * left);
-            out[2 * i + 1] = (int16_t)rint((double)s[i] * right);
+            out[2 * i] = wrap16(rint((double)s[i] * left));
+            out[2 * i + 1] = wrap16(rint((double)s[i] * right));
         }
     } else {
-        for (size_t i = 0; i < n; i++) out[i] = (int16_t)rint((double)s[i] * scale);
+        for (size_t i = 0; i < n; i++) out[i] = wrap16(rint((double)s[i] * scale));
     }
 }
 

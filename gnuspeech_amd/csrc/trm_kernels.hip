@@ -21,10 +21,14 @@ constexpr int kTileStride = kTile + 1;   // odd stride: conflict-free column wri
 
 __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *state)
 {
+    // The generator is chaotic: the product must be rounded to double before the subtraction, exactly
+    // as the reference does it (no fused multiply-add), or the sequence diverges within a few samples.
+#pragma clang fp contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double seed = state[0], x1 = state[1];
     for (uint32_t i = from; i < to; i++) {
         double prod = seed * 377.0;
+        asm volatile("" : "+v"(prod));       // opaque: keeps the rounded product, forbids v_fma_f64 fusion
         seed = prod - (double)(int)prod;
         double nz = seed - 0.5;
         lp[i] = (float)(nz + x1);
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
 
     const uint32_t nfr = A.nframes[v];
     const uint32_t nfrMax = wave_max_u32(nfr);
-    const float *frames = A.frames + A.frame_offset[v] * 16;
+    // a voice without frames (a silent no-op, TRMTubeModel.m:274-277) reads row 0 of the buffer
+    const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     float *const outBase = A.out + A.out_offset[v];
 
     const uint32_t CP = (uint32_t)C.controlPeriod;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
                 f++;
                 float prev[16];
                 for (int q = 0; q < 16; q++) prev[q] = cur[q];
-                uint32_t fi = f < nfr ? f : nfr - 1;
+                uint32_t fi = f < nfr ? f : (nfr > 0 ? nfr - 1 : 0);   // clamp: never past the voice's own rows
                 const float4 *p = reinterpret_cast<const float4 *>(frames + (size_t)fi * 16);
                 for (int q = 0; q < 4; q++) {
                     float4 x = p[q];
@@ -193,13 +198,13 @@ __global__ __launch_bounds__(256) void trm_int16_kernel(const ScaleArgs S)
         int16_t *dst = S.pcm16 + 2 * S.out_offset[v];
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             double x = (double)src[i];
-            dst[2 * i] = (int16_t)__builtin_rint(x * left);
-            dst[2 * i + 1] = (int16_t)__builtin_rint(x * right);
+            dst[2 * i] = (int16_t)(uint16_t)(int64_t)__builtin_rint(x * left);        // wraps like the reference
+            dst[2 * i + 1] = (int16_t)(uint16_t)(int64_t)__builtin_rint(x * right);
         }
     } else {
         int16_t *dst = S.pcm16 + S.out_offset[v];
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-            dst[i] = (int16_t)__builtin_rint((double)src[i] * scale);
+            dst[i] = (int16_t)(uint16_t)(int64_t)__builtin_rint((double)src[i] * scale);
     }
 }
 

@@ -189,6 +189,10 @@ int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,
  * with hipEvents on the launch stream; resets the accumulator.  Used by bench.py. */
 int  trm_batch_kernel_time_ms(trm_batch *batch, double *total_ms, uint32_t *launches);
 
+/* Diagnostic: copies the first n entries of the device-resident low-passed noise sequence
+ * (TRMUtility.m:71-85 + TRMFilters.m:81-86, generated on the GPU in fp64, stored fp32) to host. */
+int  trm_batch_noise_table(trm_batch *batch, float *host_out, size_t n);
+
 /* Library / device identification. */
 int  trm_device_count(void);
 const char *trm_build_info(void);

@@ -700,6 +700,10 @@ void trm_oracle_lp_noise(double *lp, size_t count)
 }
 
 /* ---------------------------------------------------------------- output writers */
+/* double -> int16 as the reference's x86 build does it for out-of-range values (the stereo file
+ * path over-drives a channel by up to 2x): convert to a wide integer, keep the low 16 bits. */
+static int16_t wrap16(double v) { return (int16_t)(uint16_t)(int64_t)v; }
+
 void trm_oracle_scale_int16(const trm_input_params *p, const double *s, int32_t n, double maxv,
                             int for_wav_data, int16_t *out)
 {
@@ -714,11 +718,11 @@ void trm_oracle_scale_int16(const trm_input_params *p, const double *s, int32_t 
             r = ((p->balance / 2.0) + 0.5) * scale * 2.0;
         }
         for (int32_t i = 0; i < n; i++) {
-            out[2 * i] = (int16_t)rint(s[i] * l);
-            out[2 * i + 1] = (int16_t)rint(s[i] * r);
+            out[2 * i] = wrap16(rint(s[i] * l));
+            out[2 * i + 1] = wrap16(rint(s[i] * r));
         }
     } else {
-        for (int32_t i = 0; i < n; i++) out[i] = (int16_t)rint(s[i] * scale);
+        for (int32_t i = 0; i < n; i++) out[i] = wrap16(rint(s[i] * scale));
     }
 }
 

@@ -57,6 +57,14 @@ def test_tube_model_matches_reference_fixture(g, name):
     assert abs(tube.maximumSampleValue - mx) / mx < 2e-4
 
 
+def test_noise_sequence_bit_exact(g):
+    """The chaotic generator (TRMUtility.m:71-85) + one-zero LP (TRMFilters.m:81-86) run on the GPU in
+    fp64; the stored fp32 table must equal the oracle's sequence rounded to fp32, bit for bit."""
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params()))
+    n = 60000
+    assert np.array_equal(b.noise_table(n), O.lp_noise(n).astype(np.float32))
+
+
 def _batch_vs_oracle(g, pd, voices, tol=RMS_TOL):
     ip = g.TRMInputParameters.from_dict(pd)
     b = g.TRMBatch(ip)
@@ -166,7 +174,10 @@ def test_synthesizer_facade_and_writers(g, tmp_path):
         else:
             assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE"
             body = np.frombuffer(raw[44:], dtype="<i2").astype(np.int32)
-        assert len(body) == len(ref) and np.max(np.abs(body - ref)) <= 8
+        # balance 0.3 in the file path drives the right channel past full scale (scale*2, TRMTubeModel.m:382-383):
+        # the reference's int16 cast wraps there, so compare modulo 2^16
+        diff = ((body - ref + 32768) % 65536) - 32768
+        assert len(body) == len(ref) and np.max(np.abs(diff)) <= 8
 
 
 def test_device_path_and_int16(g):
