@@ -238,7 +238,8 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     HIP_TRY(hipSetDevice(b->device));
     uint64_t ntubeMax = max_nframes > 0 ? (uint64_t)(max_nframes - 1) * (uint64_t)b->d.controlPeriod : 0;
     if (ntubeMax + 64 > 0x7FFFFFFFull) return fail(TRM_ERANGE, "utterance too long");
-    int rc = ensure_noise(b, (uint32_t)ntubeMax + 2u * (uint32_t)b->d.padSize + 8u, stream);
+    // + 2 ring halves of look-ahead that the kernel's LDS-DMA prefetch may touch
+    int rc = ensure_noise(b, (uint32_t)ntubeMax + 2u * (uint32_t)b->d.padSize + 256u, stream);
     if (rc) return rc;
     trm::TubeArgs a;
     a.frames = d_frames;
@@ -258,7 +259,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    HIP_TRY(trm::launch_tube(b->dConst, a, stream));
+    HIP_TRY(trm::launch_tube(b->c, a, stream));
     if (b->timing) {
         HIP_TRY(hipEventRecord(e1, stream));
         b->events.emplace_back(e0, e1);

@@ -11,7 +11,7 @@ namespace trm {
 // Device pointers of one batch launch.  Layout in HBM:
 //   frames        fp32 [sum nframes][16], voice v owns rows frame_offset[v] .. +nframes[v]
 //   out           fp32 PCM at output rate, voice v's samples at out + out_offset[v]
-//   lp_noise      fp32 [>= max tube samples]: the voice-independent low-passed noise sequence
+//   lp_noise      fp32 [>= max tube samples + 2*pad + 256]: the voice-independent low-passed noise sequence
 //   src_rows      fp32 [65536][16]: converter coefficients per 16-bit phase (13 used)
 //   sine          fp32 [512]
 struct TubeArgs {
@@ -41,8 +41,7 @@ struct ScaleArgs {
 };
 
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
-// c = DEVICE pointer to the batch's trm::Const
-hipError_t launch_tube(const Const *c, const TubeArgs &a, hipStream_t stream);
+hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
 
 }  // namespace trm

@@ -4,8 +4,8 @@
 //                         fp64 serial recurrence, one lane, run once per batch object and cached
 //   trm_tube_kernel       -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361): one tube per lane,
 //                         one wave (64 voices) per workgroup; state in VGPRs; wave-uniform control
-//                         in SGPRs; converter coefficients by scalar loads; output staged through
-//                         LDS and written as coalesced 256-byte rows
+//                         in SGPRs; converter coefficients + noise prefetched into LDS rings by
+//                         LDS-DMA one half ahead; output staged through LDS, written as 256-byte rows
 //   trm_int16_kernel      output normalisation (TRMTubeModel.m:370-389, 420-484)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,17 +38,22 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
     state[1] = x1;
 }
 
-struct alignas(64) SrcRow { float c[kSrcRow]; };
+// ---------------------------------------------------------------- LDS-DMA helpers
+// global_load_lds_*: asynchronous global -> LDS copy, no VGPR destination.  The LDS address is a
+// wave-uniform base (M0) + lane * size; the global source address is per lane.  Completion is
+// tracked by vmcnt; the compiler does not know these writes, so readers wait explicitly.
+typedef __attribute__((address_space(1))) const void *GlobalPtr;
+typedef __attribute__((address_space(3))) void *LdsPtr;
 
-// Wave-uniform read-only tables are read through the constant address space so that the
-// compiler emits scalar loads (s_load_dword*): one fetch per wave, no VGPRs, no VALU.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define TRM_CONST_AS __attribute__((address_space(4)))
-#else
-#define TRM_CONST_AS   /* host pass only parses the kernel */
-#endif
-typedef const SrcRow TRM_CONST_AS *ConstRowPtr;
-typedef const float TRM_CONST_AS *ConstFloatPtr;
+__device__ __forceinline__ void dma16(const float *src, float *ldsBaseUniform)
+{
+    __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)ldsBaseUniform, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const float *src, float *ldsBaseUniform)
+{
+    __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)ldsBaseUniform, 4, 0, 0);
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
@@ -59,14 +64,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-typedef const Const TRM_CONST_AS *ConstPtr;
+constexpr int kRowSlots = 64;        // converter coefficient ring: one slot per output sample
+constexpr int kRowHalf = 32;         //   refilled by halves, one half ahead
+constexpr int kSlotFloats = 32;      //   slot = left-wing row (16 floats) + right-wing row (16 floats)
+constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
+constexpr int kNoiseHalf = 64;
 
-__global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, const TubeArgs A)
+__global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
-    ConstPtr Cp = (ConstPtr)(uintptr_t)Cdev;
-    const Const C0 = *Cp;   // prologue copy (control period, converter constants)
-#define C C0
     __shared__ float sStage[kWave * kTileStride];
+    __shared__ __attribute__((aligned(16))) float sRows[kRowSlots * kSlotFloats];
+    __shared__ float sNoise[kNoiseRing];
     __shared__ float sSine[kTableLen];
 
     const int lane = threadIdx.x;
@@ -74,8 +82,10 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
 
-    for (int i = lane; i < kTableLen; i += kWave) sSine[i] = A.sine[i];
-    __syncthreads();
+    if (C.waveform != 0) {
+        for (int i = lane; i < kTableLen; i += kWave) sSine[i] = A.sine[i];
+        __syncthreads();
+    }
 
     const uint32_t nfr = A.nframes[v];
     const uint32_t nfrMax = wave_max_u32(nfr);
@@ -84,21 +94,35 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
     float *const outBase = A.out + A.out_offset[v];
 
     const uint32_t CP = (uint32_t)C.controlPeriod;
+    const uint32_t inc = C.timeRegisterIncrement;
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     uint32_t noutLane = 0;
     if (nfr > 0) {
         uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
-        noutLane = (uint32_t)((total * 65536ull + C.timeRegisterIncrement - 1) / C.timeRegisterIncrement);
+        noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
     }
     if (!laneValid) noutLane = 0;
 
     Lane L;
     Track T;
     lane_reset(L);
-
-    ConstRowPtr rows = (ConstRowPtr)(uintptr_t)A.src_rows;
-    ConstFloatPtr lpNoise = (ConstFloatPtr)(uintptr_t)A.lp_noise;
     auto sine = [&](int i) { return sSine[i]; };
+
+    // Converter coefficients for output k live in slot k & 63.  Output k's phase is (k*inc) mod 2^16
+    // (TRMSampleRateConverter.m:221-232), so rows can be fetched ahead by output index alone.
+    // One DMA instruction fills 8 slots: lane -> slot (lane>>3), 16-byte part (lane&7) = {L q0..3, R q0..3}.
+    auto fill_rows_half = [&](uint32_t kFirst, int half) {
+        for (int jj = 0; jj < 4; jj++) {
+            uint32_t k = kFirst + (uint32_t)(jj * 8 + (lane >> 3));
+            uint32_t ph = (k * inc) & 0xFFFFu;
+            uint32_t row = (lane & 4) ? 0xFFFFu - ph : ph;
+            dma16(A.src_rows + (size_t)row * kSrcRow + (lane & 3) * 4,
+                  &sRows[(half * kRowHalf + jj * 8) * kSlotFloats]);
+        }
+    };
+    auto fill_noise_half = [&](uint32_t nFirst, int half) {
+        dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
+    };
 
     if (nfrMax > 0) {
         // One flat, wave-uniform sample loop: (nfrMax-1) control periods, then the converter's
@@ -121,6 +145,12 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
                 cur[4 * q] = x.x; cur[4 * q + 1] = x.y; cur[4 * q + 2] = x.z; cur[4 * q + 3] = x.w;
             }
         }
+        fill_rows_half(0, 0);
+        fill_rows_half(kRowHalf, 1);
+        fill_noise_half(0, 0);
+        fill_noise_half(kNoiseHalf, 1);
+        dma_wait_all();
+
         for (uint32_t n = 0; n < nTotal; n++) {
             if (j == CP) {   // -setControlRateParameters:previous: (TRMTubeModel.m:289)
                 j = 0;
@@ -135,25 +165,34 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
                 }
                 track_setup(T, C, prev, cur);
             }
-            // Re-read the constants through the scalar cache every sample instead of keeping ~90
-            // SGPRs live across the loop (which spills them into VGPR lanes: v_readlane per use).
-            asm volatile("" : "+s"(Cp));
-            const Const Cs = *Cp;
-            float s = lane_sample(L, T, Cs, (int)j, lpNoise[n], sine);
+            if ((n & (kNoiseHalf - 1)) == 0 && n > 0) {
+                // entering a noise half: its samples were requested one half ago; refill the other half
+                dma_wait_all();
+                fill_noise_half(n + kNoiseHalf, ((n / kNoiseHalf) + 1) & 1);
+            }
+            float s = lane_sample(L, T, C, (int)j, sNoise[n & (kNoiseRing - 1)], sine);
             j++;
             s = n < ntubeLane ? s : 0.0f;
             src_push(L, s);
             while (e <= n) {     // TRMSampleRateConverter.m:171-233, uniform trip count
-                const uint32_t ph = t & 0xFFFFu;
-                const SrcRow rl = rows[ph];
-                const SrcRow rr = rows[0xFFFFu - ph];
-                float y = src_emit_up(L, rl.c, rr.c);
+                if ((kout & (kRowHalf - 1)) == 0 && kout > 0) {
+                    dma_wait_all();
+                    fill_rows_half(kout + kRowHalf, ((kout / kRowHalf) + 1) & 1);
+                }
+                const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(kout & (kRowSlots - 1)) * kSlotFloats]);
+                float cl[16], cr[16];
+                for (int q = 0; q < 4; q++) {
+                    float4 a = rp[q], b = rp[4 + q];
+                    cl[4 * q] = a.x; cl[4 * q + 1] = a.y; cl[4 * q + 2] = a.z; cl[4 * q + 3] = a.w;
+                    cr[4 * q] = b.x; cr[4 * q + 1] = b.y; cr[4 * q + 2] = b.z; cr[4 * q + 3] = b.w;
+                }
+                float y = src_emit_up(L, cl, cr);
                 float a = fabsf(y);
                 L.maxAbs = (kout < noutLane && a > L.maxAbs) ? a : L.maxAbs;
                 sStage[lane * kTileStride + tilePos] = y;
                 tilePos++;
                 kout++;
-                t += C.timeRegisterIncrement;
+                t += inc;
                 e += t >> 16;
                 t &= 0xFFFFu;
                 if (tilePos == kTile || (e > n && n + 1 == nTotal)) {
@@ -173,13 +212,13 @@ __global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const *Cdev, cons
                 }
             }
         }
+        dma_wait_all();   // nothing may still be writing LDS when the wave ends
     }
 
     if (laneValid) {
         A.number_samples[vRaw] = noutLane;
         A.max_sample[vRaw] = L.maxAbs;
     }
-#undef C
 }
 
 // Output normalisation (TRMTubeModel.m:370-389 file path, :515-533 WAV-data path).  One
@@ -215,7 +254,7 @@ hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hi
     return hipGetLastError();
 }
 
-hipError_t launch_tube(const Const *c, const TubeArgs &a, hipStream_t stream)
+hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kWave - 1) / kWave;
