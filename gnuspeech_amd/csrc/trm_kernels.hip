@@ -2,10 +2,11 @@
 //
 //   trm_noise_kernel      the voice-independent noise sequence (TRMUtility.m:71-85 + TRMFilters.m:81-86),
 //                         fp64 serial recurrence, one lane, run once per batch object and cached
-//   trm_tube_kernel       -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361): one tube per lane,
-//                         one wave (64 voices) per workgroup; state in VGPRs; wave-uniform control
-//                         in SGPRs; converter coefficients + noise prefetched into LDS rings by
-//                         LDS-DMA one half ahead; output staged through LDS, written as 256-byte rows
+//   trm_tube_kernel       -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361): one tube per lane, 64 voices
+//                         per workgroup, 4 waves per workgroup running the sample loop as a pipeline
+//                         (excite | coef | tube | convert) with hand-offs through LDS; state in VGPRs;
+//                         wave-uniform control in SGPRs; converter coefficients + noise prefetched into
+//                         LDS rings by LDS-DMA one half ahead; output staged through LDS, written as rows
 //   trm_int16_kernel      output normalisation (TRMTubeModel.m:370-389, 420-484)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,8 +17,15 @@
 namespace trm {
 
 constexpr int kWave = 64;
-constexpr int kTile = 64;            // outputs staged per lane before a flush
+constexpr int kRoles = 4;            // waves per workgroup: excite, coef, tube, convert
+constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
+constexpr int kTile = 32;            // outputs staged per lane before a flush (128-byte rows)
 constexpr int kTileStride = kTile + 1;   // odd stride: conflict-free column writes and row reads
+constexpr int kRowSlots = 64;        // converter coefficient ring: one slot per output sample
+constexpr int kRowHalf = 32;         //   refilled by halves, one half ahead
+constexpr int kSlotFloats = 32;      //   slot = left-wing row (16 floats) + right-wing row (16 floats)
+constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
+constexpr int kNoiseHalf = 64;
 
 __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *state)
 {
@@ -64,160 +72,246 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-constexpr int kRowSlots = 64;        // converter coefficient ring: one slot per output sample
-constexpr int kRowHalf = 32;         //   refilled by halves, one half ahead
-constexpr int kSlotFloats = 32;      //   slot = left-wing row (16 floats) + right-wing row (16 floats)
-constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
-constexpr int kNoiseHalf = 64;
-
-__global__ __launch_bounds__(kWave) void trm_tube_kernel(const Const C, const TubeArgs A)
+__device__ __forceinline__ void load_frame(const float *frames, uint32_t fi, float *dst, int quads)
 {
-    __shared__ float sStage[kWave * kTileStride];
-    __shared__ __attribute__((aligned(16))) float sRows[kRowSlots * kSlotFloats];
-    __shared__ float sNoise[kNoiseRing];
-    __shared__ float sSine[kTableLen];
+    const float4 *p = reinterpret_cast<const float4 *>(frames + (size_t)fi * 16);
+    for (int q = 0; q < quads; q++) {
+        float4 x = p[q];
+        dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w;
+    }
+}
 
-    const int lane = threadIdx.x;
+// One workgroup = 64 voices (one per lane) x 4 waves (one per pipeline stage).  At step i the
+// excite and coef waves produce block i (kTB tube samples) into LDS, the tube wave consumes block
+// i-1 and produces tube-rate samples, the convert wave consumes block i-2 and writes PCM.  One
+// barrier per step; every hand-off buffer is double-buffered.
+__global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, const TubeArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // excitation per sample
+    __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * 6 * kWave];      // coefficients per sample
+    __shared__ float sY[2 * kTB * kWave];                                        // tube-rate samples
+    __shared__ float sStage[kWave * kTileStride];                                // convert: output tile
+    __shared__ __attribute__((aligned(16))) float sRows[kRowSlots * kSlotFloats]; // convert: coefficient ring
+    __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
+    __shared__ float sSine[kTableLen];                                           // excite: sine table
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t vRaw = blockIdx.x * kWave + lane;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
 
-    if (C.waveform != 0) {
-        for (int i = lane; i < kTableLen; i += kWave) sSine[i] = A.sine[i];
-        __syncthreads();
-    }
-
     const uint32_t nfr = A.nframes[v];
-    const uint32_t nfrMax = wave_max_u32(nfr);
+    const uint32_t nfrMax = wave_max_u32(nfr);          // same 64 voices in every wave of the group
+    const uint32_t CP = (uint32_t)C.controlPeriod;
+    const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
+    // (nfrMax-1) control periods, then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93).
+    // Lanes whose utterance is shorter than the group's longest keep stepping on their last frame;
+    // the convert stage forces their converter input to 0 and masks their stores.
+    const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 2 : 0;
     // a voice without frames (a silent no-op, TRMTubeModel.m:274-277) reads row 0 of the buffer
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
-    float *const outBase = A.out + A.out_offset[v];
 
-    const uint32_t CP = (uint32_t)C.controlPeriod;
-    const uint32_t inc = C.timeRegisterIncrement;
-    const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
-    uint32_t noutLane = 0;
-    if (nfr > 0) {
-        uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
-        noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
-    }
-    if (!laneValid) noutLane = 0;
-
-    Lane L;
-    Track T;
-    lane_reset(L);
-    auto sine = [&](int i) { return sSine[i]; };
-
-    // Converter coefficients for output k live in slot k & 63.  Output k's phase is (k*inc) mod 2^16
-    // (TRMSampleRateConverter.m:221-232), so rows can be fetched ahead by output index alone.
-    // One DMA instruction fills 8 slots: lane -> slot (lane>>3), 16-byte part (lane&7) = {L q0..3, R q0..3}.
-    auto fill_rows_half = [&](uint32_t kFirst, int half) {
-        for (int jj = 0; jj < 4; jj++) {
-            uint32_t k = kFirst + (uint32_t)(jj * 8 + (lane >> 3));
-            uint32_t ph = (k * inc) & 0xFFFFu;
-            uint32_t row = (lane & 4) ? 0xFFFFu - ph : ph;
-            dma16(A.src_rows + (size_t)row * kSrcRow + (lane & 3) * 4,
-                  &sRows[(half * kRowHalf + jj * 8) * kSlotFloats]);
+    if (role == 0) {
+        // ------------------------------------------------------------ excite
+        if (C.waveform != 0)
+            for (int i = lane; i < kTableLen; i += kWave) sSine[i] = A.sine[i];
+        auto sine = [&](int i) { return sSine[i]; };
+        auto fill_noise_half = [&](uint32_t nFirst, int half) {
+            dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
+        };
+        ExciteState S;
+        ExciteTrack T;
+        excite_reset(S);
+        float cur[4], prev[4];
+        if (nSteps > 0) {
+            load_frame(frames, 0, cur, 1);
+            fill_noise_half(0, 0);
+            fill_noise_half(kNoiseHalf, 1);
+            dma_wait_all();
         }
-    };
-    auto fill_noise_half = [&](uint32_t nFirst, int half) {
-        dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
-    };
-
-    if (nfrMax > 0) {
-        // One flat, wave-uniform sample loop: (nfrMax-1) control periods, then the converter's
-        // 2*pad zero flush (TRMRingBuffer.m:85-93).  Lanes whose utterance is shorter than the
-        // wave's longest keep stepping on their last frame; their converter input is forced to 0
-        // and their stores are masked by their own output count.
-        const uint32_t ntubeMax = (nfrMax - 1) * CP;
-        const uint32_t nTotal = ntubeMax + 2u * (uint32_t)C.padSize;
+        uint32_t j = CP, f = 0;
+        for (uint32_t step = 0; step < nSteps; step++) {
+            const int buf = step & 1;
+            for (int u = 0; u < kTB; u++) {
+                const uint32_t n = step * kTB + u;
+                if (n < nTotal) {
+                    if (j == CP) {   // -setControlRateParameters:previous: (TRMTubeModel.m:289)
+                        j = 0;
+                        f++;
+                        for (int q = 0; q < 4; q++) prev[q] = cur[q];
+                        load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 1);
+                        excite_track_setup(T, C, prev, cur);
+                    }
+                    if ((n & (kNoiseHalf - 1)) == 0 && n > 0) {
+                        // entering a noise half: it was requested one half ago; refill the other half
+                        dma_wait_all();
+                        fill_noise_half(n + kNoiseHalf, ((n / kNoiseHalf) + 1) & 1);
+                    }
+                    Excitation E = excite_sample(S, T, C, (int)j, sNoise[n & (kNoiseRing - 1)], sine);
+                    j++;
+                    sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                }
+            }
+            __syncthreads();
+        }
+        dma_wait_all();   // nothing may still be writing LDS when the wave ends
+    } else if (role == 1) {
+        // ------------------------------------------------------------ coef
+        CoefTrack T;
+        float cur[16], prev[16];
+        if (nSteps > 0) load_frame(frames, 0, cur, 4);
+        uint32_t j = CP, f = 0;
+        for (uint32_t step = 0; step < nSteps; step++) {
+            const int buf = step & 1;
+            for (int u = 0; u < kTB; u++) {
+                const uint32_t n = step * kTB + u;
+                if (n < nTotal) {
+                    if (j == CP) {
+                        j = 0;
+                        f++;
+                        for (int q = 0; q < 16; q++) prev[q] = cur[q];
+                        load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 4);
+                        coef_track_setup(T, C, prev, cur);
+                    }
+                    Coefs K = coef_sample(T, C, (int)j);
+                    j++;
+                    float4 *dst = &sK[((buf * kTB + u) * 6) * kWave + lane];
+                    dst[0 * kWave] = make_float4(K.k[0], K.k[1], K.k[2], K.k[3]);
+                    dst[1 * kWave] = make_float4(K.k[4], K.k[5], K.k[6], K.k[7]);
+                    dst[2 * kWave] = make_float4(K.onePlusK8, K.alphaLR, K.alphaU, K.nk1);
+                    dst[3 * kWave] = make_float4(K.tap[0], K.tap[1], K.tap[2], K.tap[3]);
+                    dst[4 * kWave] = make_float4(K.tap[4], K.tap[5], K.tap[6], K.tap[7]);
+                    dst[5 * kWave] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
+                }
+            }
+            __syncthreads();
+        }
+    } else if (role == 2) {
+        // ------------------------------------------------------------ tube
+        TubeState S;
+        tube_reset(S);
+        for (uint32_t step = 0; step < nSteps; step++) {
+            if (step >= 1) {
+                const uint32_t blk = step - 1;
+                const int buf = blk & 1;
+                for (int u = 0; u < kTB; u++) {
+                    const uint32_t n = blk * kTB + u;
+                    if (n < nTotal) {
+                        const float4 x = sX[(buf * kTB + u) * kWave + lane];
+                        const float4 *src = &sK[((buf * kTB + u) * 6) * kWave + lane];
+                        const float4 k0 = src[0 * kWave], k1 = src[1 * kWave], k2 = src[2 * kWave];
+                        const float4 t0 = src[3 * kWave], t1 = src[4 * kWave], bp = src[5 * kWave];
+                        Excitation E;
+                        E.gin = x.x; E.sig = x.y; E.thr = x.z;
+                        Coefs K;
+                        K.k[0] = k0.x; K.k[1] = k0.y; K.k[2] = k0.z; K.k[3] = k0.w;
+                        K.k[4] = k1.x; K.k[5] = k1.y; K.k[6] = k1.z; K.k[7] = k1.w;
+                        K.onePlusK8 = k2.x; K.alphaLR = k2.y; K.alphaU = k2.z; K.nk1 = k2.w;
+                        K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
+                        K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
+                        K.bpAlpha = bp.x; K.bpBeta = bp.y; K.bpGamma = bp.z; K.pad_ = 0.0f;
+                        sY[(buf * kTB + u) * kWave + lane] = tube_sample(S, C, E, K);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ------------------------------------------------------------ convert
+        float *const outBase = A.out + A.out_offset[v];
+        const uint32_t inc = C.timeRegisterIncrement;
+        const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
+        uint32_t noutLane = 0;
+        if (nfr > 0) {
+            uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
+            noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
+        }
+        if (!laneValid) noutLane = 0;
+        SrcState S;
+        src_reset(S);
+        // Converter coefficients for output k live in slot k & 63.  Output k's phase is (k*inc) mod 2^16
+        // (TRMSampleRateConverter.m:221-232), so rows can be fetched ahead by output index alone.
+        // One DMA instruction fills 8 slots: lane -> slot (lane>>3), 16-byte part (lane&7) = {L q0..3, R q0..3}.
+        auto fill_rows_half = [&](uint32_t kFirst, int half) {
+            for (int jj = 0; jj < 4; jj++) {
+                uint32_t k = kFirst + (uint32_t)(jj * 8 + (lane >> 3));
+                uint32_t ph = (k * inc) & 0xFFFFu;
+                uint32_t row = (lane & 4) ? 0xFFFFu - ph : ph;
+                dma16(A.src_rows + (size_t)row * kSrcRow + (lane & 3) * 4,
+                      &sRows[(half * kRowHalf + jj * 8) * kSlotFloats]);
+            }
+        };
+        if (nSteps > 0) {
+            fill_rows_half(0, 0);
+            fill_rows_half(kRowHalf, 1);
+            dma_wait_all();
+        }
         uint32_t e = 0;          // converter read position, in pushed samples (uniform)
         uint32_t t = 0;          // 16.16 time register, N part cleared (uniform)
         uint32_t kout = 0;       // outputs emitted (uniform)
         uint32_t tilePos = 0;    // outputs staged in LDS (uniform)
-        uint32_t j = CP;         // position in the control period (uniform)
-        uint32_t f = 0;          // index of the period's target frame (uniform)
-        float cur[16];
-        {
-            const float4 *p = reinterpret_cast<const float4 *>(frames);
-            for (int q = 0; q < 4; q++) {
-                float4 x = p[q];
-                cur[4 * q] = x.x; cur[4 * q + 1] = x.y; cur[4 * q + 2] = x.z; cur[4 * q + 3] = x.w;
-            }
-        }
-        fill_rows_half(0, 0);
-        fill_rows_half(kRowHalf, 1);
-        fill_noise_half(0, 0);
-        fill_noise_half(kNoiseHalf, 1);
-        dma_wait_all();
-
-        for (uint32_t n = 0; n < nTotal; n++) {
-            if (j == CP) {   // -setControlRateParameters:previous: (TRMTubeModel.m:289)
-                j = 0;
-                f++;
-                float prev[16];
-                for (int q = 0; q < 16; q++) prev[q] = cur[q];
-                uint32_t fi = f < nfr ? f : (nfr > 0 ? nfr - 1 : 0);   // clamp: never past the voice's own rows
-                const float4 *p = reinterpret_cast<const float4 *>(frames + (size_t)fi * 16);
-                for (int q = 0; q < 4; q++) {
-                    float4 x = p[q];
-                    cur[4 * q] = x.x; cur[4 * q + 1] = x.y; cur[4 * q + 2] = x.z; cur[4 * q + 3] = x.w;
-                }
-                track_setup(T, C, prev, cur);
-            }
-            if ((n & (kNoiseHalf - 1)) == 0 && n > 0) {
-                // entering a noise half: its samples were requested one half ago; refill the other half
-                dma_wait_all();
-                fill_noise_half(n + kNoiseHalf, ((n / kNoiseHalf) + 1) & 1);
-            }
-            float s = lane_sample(L, T, C, (int)j, sNoise[n & (kNoiseRing - 1)], sine);
-            j++;
-            s = n < ntubeLane ? s : 0.0f;
-            src_push(L, s);
-            while (e <= n) {     // TRMSampleRateConverter.m:171-233, uniform trip count
-                if ((kout & (kRowHalf - 1)) == 0 && kout > 0) {
-                    dma_wait_all();
-                    fill_rows_half(kout + kRowHalf, ((kout / kRowHalf) + 1) & 1);
-                }
-                const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(kout & (kRowSlots - 1)) * kSlotFloats]);
-                float cl[16], cr[16];
-                for (int q = 0; q < 4; q++) {
-                    float4 a = rp[q], b = rp[4 + q];
-                    cl[4 * q] = a.x; cl[4 * q + 1] = a.y; cl[4 * q + 2] = a.z; cl[4 * q + 3] = a.w;
-                    cr[4 * q] = b.x; cr[4 * q + 1] = b.y; cr[4 * q + 2] = b.z; cr[4 * q + 3] = b.w;
-                }
-                float y = src_emit_up(L, cl, cr);
-                float a = fabsf(y);
-                L.maxAbs = (kout < noutLane && a > L.maxAbs) ? a : L.maxAbs;
-                sStage[lane * kTileStride + tilePos] = y;
-                tilePos++;
-                kout++;
-                t += inc;
-                e += t >> 16;
-                t &= 0xFFFFu;
-                if (tilePos == kTile || (e > n && n + 1 == nTotal)) {
-                    // flush the staged tile: row r = voice of lane r, 256 contiguous bytes per row
-                    const uint32_t kbase = kout - tilePos;
+        for (uint32_t step = 0; step < nSteps; step++) {
+            if (step >= 2) {
+                const uint32_t blk = step - 2;
+                const int buf = blk & 1;
+                for (int u = 0; u < kTB; u++) {
+                    const uint32_t n = blk * kTB + u;
+                    if (n < nTotal) {
+                        float s = sY[(buf * kTB + u) * kWave + lane];
+                        s = n < ntubeLane ? s : 0.0f;
+                        src_push(S, s);
+                        while (e <= n) {     // TRMSampleRateConverter.m:171-233, uniform trip count
+                            if ((kout & (kRowHalf - 1)) == 0 && kout > 0) {
+                                dma_wait_all();
+                                fill_rows_half(kout + kRowHalf, ((kout / kRowHalf) + 1) & 1);
+                            }
+                            const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(kout & (kRowSlots - 1)) * kSlotFloats]);
+                            float cl[16], cr[16];
+                            for (int q = 0; q < 4; q++) {
+                                float4 a = rp[q], b = rp[4 + q];
+                                cl[4 * q] = a.x; cl[4 * q + 1] = a.y; cl[4 * q + 2] = a.z; cl[4 * q + 3] = a.w;
+                                cr[4 * q] = b.x; cr[4 * q + 1] = b.y; cr[4 * q + 2] = b.z; cr[4 * q + 3] = b.w;
+                            }
+                            float y = src_emit_up(S, cl, cr);
+                            float a = fabsf(y);
+                            S.maxAbs = (kout < noutLane && a > S.maxAbs) ? a : S.maxAbs;
+                            sStage[lane * kTileStride + tilePos] = y;
+                            tilePos++;
+                            kout++;
+                            t += inc;
+                            e += t >> 16;
+                            t &= 0xFFFFu;
+                            if (tilePos == kTile || (e > n && n + 1 == nTotal)) {
+                                // flush the staged tile: row r = voice of lane r, contiguous per row
+                                const uint32_t kbase = kout - tilePos;
 #pragma unroll 1
-                    for (int r = 0; r < kWave; r++) {
-                        uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uintptr_t)outBase, r);
-                        uint32_t hi = __builtin_amdgcn_readlane((uint32_t)((uintptr_t)outBase >> 32), r);
-                        uint32_t nr = __builtin_amdgcn_readlane(noutLane, r);
-                        float *dst = reinterpret_cast<float *>(((uintptr_t)hi << 32) | lo);
-                        float val = sStage[r * kTileStride + lane];
-                        uint32_t k = kbase + (uint32_t)lane;
-                        if ((uint32_t)lane < tilePos && k < nr) dst[k] = val;
+                                for (int r = 0; r < kWave; r += 2) {
+                                    // lanes 0..31 write row r, lanes 32..63 write row r+1
+                                    const int rr = r + (lane >> 5);
+                                    uint32_t lo = __shfl((uint32_t)(uintptr_t)outBase, rr, kWave);
+                                    uint32_t hi = __shfl((uint32_t)((uintptr_t)outBase >> 32), rr, kWave);
+                                    uint32_t nr = __shfl(noutLane, rr, kWave);
+                                    float *dst = reinterpret_cast<float *>(((uintptr_t)hi << 32) | lo);
+                                    const uint32_t col = (uint32_t)(lane & 31);
+                                    float val = sStage[rr * kTileStride + col];
+                                    uint32_t k = kbase + col;
+                                    if (col < tilePos && k < nr) dst[k] = val;
+                                }
+                                tilePos = 0;
+                            }
+                        }
                     }
-                    tilePos = 0;
                 }
             }
+            __syncthreads();
         }
-        dma_wait_all();   // nothing may still be writing LDS when the wave ends
-    }
-
-    if (laneValid) {
-        A.number_samples[vRaw] = noutLane;
-        A.max_sample[vRaw] = L.maxAbs;
+        dma_wait_all();
+        if (laneValid) {
+            A.number_samples[vRaw] = noutLane;
+            A.max_sample[vRaw] = S.maxAbs;
+        }
     }
 }
 
@@ -258,7 +352,7 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kWave - 1) / kWave;
-    hipLaunchKernelGGL(trm_tube_kernel, dim3(grid), dim3(kWave), 0, stream, c, a);
+    hipLaunchKernelGGL(trm_tube_kernel, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
     return hipGetLastError();
 }
 

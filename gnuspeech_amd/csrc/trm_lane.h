@@ -1,14 +1,23 @@
 // trm_lane.h -- the per-lane Tube Resonance Model: ONE tube voice per GPU lane.
 //
 // This is the arithmetic of -[TRMTubeModel synthesize]'s sample loop
-// (Frameworks/Tube/TRMTubeModel.m:292-354) re-designed for a 64-wide CDNA4 wavefront:
-//   * every lane owns one tube; all state lives in VGPRs (no per-lane tables);
-//   * everything that is identical for all voices of a batch (sample index, control-period
-//     position, sample-rate-converter phase, noise sequence, filter taps) is wave-uniform and
-//     lives in SGPRs / scalar loads;
-//   * fp32 for the signal path; fp64 only where the reference has a discontinuity
-//     (oscillator phase wrap, rint() of the glottal closure point, (int) of the frication
-//     position, dB clamps) -- SURVEY.md 9.4.
+// (Frameworks/Tube/TRMTubeModel.m:292-354) re-designed for 64-wide CDNA4 wavefronts.  A voice
+// never leaves its lane, but the loop is cut into four stages that different waves of one
+// workgroup run as a pipeline (the stage boundaries are exactly the feed-forward cuts of the
+// reference's data flow):
+//
+//   excite   control tracks (pitch, voicing, aspiration) -> glottal oscillator -> 49-tap FIR ->
+//            noise mixing  => {tract input, noise signal for the frication filter, throat input}
+//   coef     control tracks (radii, velum, frication)  -> scattering coefficients, frication
+//            taps, band-pass coefficients
+//   tube     the recurrences: frication band-pass, 10+6 section waveguide, mouth/nose
+//            reflection+radiation filters, throat low-pass  => one tube-rate sample
+//   convert  band-limited sample-rate conversion to the output rate
+//
+// Everything that is identical for all voices of a batch (sample index, control-period position,
+// converter phase, noise sequence, filter taps) is wave-uniform.  fp32 carries the signal; fp64 is
+// used only where the reference has a discontinuity (oscillator phase wrap, rint() of the glottal
+// closure point, (int) of the frication position, dB clamps) -- SURVEY.md 9.4.
 //
 // The same header compiles for the device (HIP, gfx950) and, for numerics tests only, for the
 // host (tests/_emul).  No product path runs the host build.
@@ -34,7 +43,7 @@ constexpr int kFirUnique = 25;      // 49 symmetric taps (TRMFIRFilter.h:7-9 des
 constexpr int kFirTaps = 49;
 constexpr int kSrcWing = 13;        // ZERO_CROSSINGS (TRMSampleRateConverter.m:10)
 constexpr int kSrcWindow = 26;
-constexpr int kSrcRow = 16;         // coefficient row, 13 used + 3 pad (one s_load_dwordx16)
+constexpr int kSrcRow = 16;         // coefficient row, 13 used + 3 pad
 constexpr int kTableLen = 512;      // TRMWavetable.m:22
 constexpr float kVtScale = 0.125f;  // TRMTubeModel.m:72
 
@@ -88,8 +97,10 @@ struct Const {
     float onePlusNK6;           // 1 + NC6, formed in double                 (:849)
     float noseR1sq;             // noseRadius[1]^2, for NC1                  (:741)
     float apScaleSq;            // apScale^2, for C8                         (:724)
-    float mA10, mB11, mA20, mA21, mB21;   // mouth reflection/radiation pair (TRMFilters.m:34-45)
-    float nA10, nB11, nA20, nA21, nB21;   // nose pair
+    // mouth / nose reflection+radiation pairs (TRMFilters.m:34-45): a20 = coeff, a21 = b21 = b11 =
+    // -coeff, a10 = 1 - |coeff|
+    float mCoeff, mA10;
+    float nCoeff, nA10;
     float ta0, tb1, throatGain;           // throat low-pass                 (TRMFilters.m:64-68)
     float invSampleRate;
     // glottal pulse table geometry (TRMWavetable.m:71-75)
@@ -104,52 +115,37 @@ struct Const {
     uint32_t phaseIncrement;    // down-sampling only
     int32_t padSize;
     int32_t upsample;           // sampleRateRatio >= 1
-    float sampleRateRatio;      // for the down-sampling phase computation (double on host)
     double sampleRateRatioD;
 };
 
-// Per-lane control-period interpolation state (TRMTubeModel.m:611-688).  Columns follow the
-// frame order of TRMDataList.m:223-233.
-struct Track {
-    // fp64: the three columns that feed quantisers / the phase accumulator
+// ================================================================ stage 1: excitation
+// Control-period interpolation state of the columns this stage consumes (TRMTubeModel.m:611-688).
+struct ExciteTrack {
     double f0, f0Ratio;         // 220*2^((pitch+3)/12) as a geometric sequence per sample
     double glotDb, glotDbDelta; // dB value, repeated addition like the reference
     double axGeo, axRatio;      // 10^((dB-60)/20) as a geometric sequence
-    double fricPos, fricPosDelta;
-    // fp32 direct interpolation base + delta: aspVol, fricVol, fricCF, fricBW, r1..r8, velum
-    float base[13], delta[13];
+    float aspBase, aspDelta;    // aspiration volume, dB
 };
 
-struct Lane {
-    // waveguide: travelling-wave values of the previous sample (TRMTubeModel.m:161-165)
-    wg_t oT[10], oB[10];        // oropharynx top / bottom
-    wg_t nT[6], nB[6];          // nasal
-    wg_t mReflY, mRadX, mRadY;  // mouth filter memories
-    wg_t nReflY, nRadX, nRadY;  // nose filter memories
-    wg_t throatY;
-    float bpX1, bpX2, bpY1, bpY2;   // frication band-pass memory (TRMFilters.m:19-29)
+struct ExciteState {
     double oscPos;              // wavetable position (TRMWavetable.m:165-168)
     float fir[24];              // transposed-form partial sums of the 49-tap FIR
-    float src[kSrcWindow];      // last 26 tube-rate samples, src[25] newest
-    float maxAbs;
 };
 
-TRM_HD void lane_reset(Lane &L)
+struct Excitation {
+    float gin;                  // (pulse + ah1*signal) * VT_SCALE : tract input      (:336)
+    float sig;                  // noise signal fed to the frication band-pass        (:337)
+    float thr;                  // pulse * VT_SCALE : throat input                    (:341)
+};
+
+TRM_HD void excite_reset(ExciteState &S)
 {
-    for (int i = 0; i < 10; i++) { L.oT[i] = 0.f; L.oB[i] = 0.f; }
-    for (int i = 0; i < 6; i++) { L.nT[i] = 0.f; L.nB[i] = 0.f; }
-    L.mReflY = L.mRadX = L.mRadY = 0.f;
-    L.nReflY = L.nRadX = L.nRadY = 0.f;
-    L.throatY = 0.f;
-    L.bpX1 = L.bpX2 = L.bpY1 = L.bpY2 = 0.f;
-    L.oscPos = 0.0;
-    for (int i = 0; i < 24; i++) L.fir[i] = 0.f;
-    for (int i = 0; i < kSrcWindow; i++) L.src[i] = 0.f;
-    L.maxAbs = 0.f;
+    S.oscPos = 0.0;
+    for (int i = 0; i < 24; i++) S.fir[i] = 0.f;
 }
 
-// -setControlRateParameters:previous: (TRMTubeModel.m:611-672).  prev/cur = 16 fp32 frame values.
-TRM_HD void track_setup(Track &T, const Const &C, const float *prev, const float *cur)
+// -setControlRateParameters:previous: (TRMTubeModel.m:611-672), columns pitch / glotVol / aspVol.
+TRM_HD void excite_track_setup(ExciteTrack &T, const Const &C, const float *prev, const float *cur)
 {
     const double kLog2_10_over_20 = 0.16609640474436813;   // log2(10)/20
     double p0 = (double)prev[0], dp = ((double)cur[0] - p0) * C.invControlPeriodD;
@@ -160,13 +156,8 @@ TRM_HD void track_setup(Track &T, const Const &C, const float *prev, const float
     T.glotDbDelta = dv;
     T.axGeo = exp2_d((v0 - 60.0) * kLog2_10_over_20);      // amplitude(), TRMUtility.m:26-41
     T.axRatio = exp2_d(dv * kLog2_10_over_20);
-    T.fricPos = (double)prev[4];
-    T.fricPosDelta = ((double)cur[4] - T.fricPos) / (double)C.controlPeriod;
-    const int col[13] = {2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
-    for (int i = 0; i < 13; i++) {
-        T.base[i] = prev[col[i]];
-        T.delta[i] = (cur[col[i]] - prev[col[i]]) * C.invControlPeriod;
-    }
+    T.aspBase = prev[2];
+    T.aspDelta = (cur[2] - prev[2]) * C.invControlPeriod;
 }
 
 // dB -> linear amplitude with the reference's clamps (TRMUtility.m:26-41), fp32.
@@ -189,88 +180,26 @@ TRM_HD float pulse_table(int i, const Const &C, int newDiv2, float invFall)
     return i < C.tableDiv1 ? rise : v;
 }
 
-// The per-sample update.  `j` = position in the control period (uniform), `lpNoise` = the
-// voice-independent low-passed noise sample (uniform), `sineTab` = 512-entry sine table or null.
-// Returns the tube-rate output sample (what the reference hands to -dataFill:, :346).
+// `j` = position in the control period (uniform), `lpNoise` = the voice-independent low-passed
+// noise sample (uniform), `sineTab` = 512-entry sine table lookup.
 template <class SineLookup>
-TRM_HD float lane_sample(Lane &L, Track &T, const Const &C, int j, float lpNoise, SineLookup sineTab)
+TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, int j, float lpNoise, SineLookup sineTab)
 {
-    const float fj = (float)j;
-    // ---- control-rate interpolation, fp32 columns (:676-688 evaluated as base + j*delta)
-    float aspDb = fma_f(fj, T.delta[0], T.base[0]);
-    float fricDb = fma_f(fj, T.delta[1], T.base[1]);
-    float fricCF = fma_f(fj, T.delta[2], T.base[2]);
-    float fricBW = fma_f(fj, T.delta[3], T.base[3]);
-    float r[8];
-    for (int i = 0; i < 8; i++) r[i] = fma_f(fj, T.delta[4 + i], T.base[4 + i]);
-    float velum = fma_f(fj, T.delta[12], T.base[12]);
-
-    // ---- fp64 columns: amplitude of voicing with its clamps, closure point, pitch (:294-296)
+    // amplitude of voicing with its clamps (:294-296), in fp64: it feeds rint() below
     double axd = T.glotDb >= 60.0 ? 1.0 : T.axGeo;
     axd = T.glotDb <= 0.0 ? 0.0 : axd;
     const float ax = (float)axd;
-    const float ah1 = amplitude_f(aspDb);
+    const float ah1 = amplitude_f(fma_f((float)j, T.aspDelta, T.aspBase));
 
-    // ---- scattering coefficients (:712-744)
-    float r2[8];
-    for (int i = 0; i < 8; i++) r2[i] = r[i] * r[i];
-    float k[8];
-    for (int i = 0; i < 7; i++) k[i] = (r2[i] - r2[i + 1]) * rcp_f(r2[i] + r2[i + 1]);
-    float rk8 = rcp_f(r2[7] + C.apScaleSq);
-    k[7] = (r2[7] - C.apScaleSq) * rk8;
-    float onePlusK8 = (r2[7] + r2[7]) * rk8;     // 1 + C8 without the cancellation of a nearly closed mouth
-    float v2 = velum * velum;
-    float jsum = 2.0f * rcp_f(r2[3] + r2[3] + v2);
-    float alphaLR = jsum * r2[3];
-    float alphaU = jsum * v2;
-    float nk1 = (v2 - C.noseR1sq) * rcp_f(v2 + C.noseR1sq);
-
-    // ---- frication taps (:748-773)
-    float fricAmp = amplitude_f(fricDb);
-    int ip = (int)T.fricPos;
-    float comp = (float)(T.fricPos - (double)ip);
-    float tapA = (1.0f - comp) * fricAmp;       // tap[ip]
-    float tapB = comp * fricAmp;                // tap[ip+1] when ip+1 < 8
-    float tap[8];
-    tap[0] = ip == 0 ? tapA : 0.0f;
-    for (int i = 1; i < 8; i++) {
-        float t = i == ip ? tapA : 0.0f;
-        tap[i] = i - 1 == ip ? tapB : t;
-    }
-
-    // ---- band-pass coefficients (TRMFilters.m:9-17): tan(pi*BW/SR), cos(2*pi*CF/SR)
-    float bpBeta, bpGamma, bpAlpha;
-    {
-        float v = fricBW * C.invSampleRate;
-        v = v - rint_f(v);                      // tan has period 1 in v
-        float a = fabsf(v);
-        bool hi = a > 0.25f;
-        float y = 3.14159265358979f * (hi ? 0.5f - a : a);
-        float s = sin_q(y), c = cos_q(y);
-        float num = hi ? c : s, den = hi ? s : c;     // tan = num/den
-        num = v < 0.0f ? -num : num;
-        bpBeta = (den - num) * rcp_f(2.0f * (den + num));   // (1-t)/(2(1+t))
-        float u = fricCF * C.invSampleRate;
-        u = fabsf(u - rint_f(u));               // [0, .5]
-        bool neg = u > 0.25f;
-        u = neg ? 0.5f - u : u;                 // [0, .25]: angle in [0, pi/2]
-        bool swap = u > 0.125f;
-        float yy = 6.28318530717959f * (swap ? 0.25f - u : u);
-        float cv = swap ? sin_q(yy) : cos_q(yy);
-        cv = neg ? -cv : cv;
-        bpGamma = (0.5f + bpBeta) * cv;
-        bpAlpha = (0.5f - bpBeta) * 0.5f;
-    }
-
-    // ---- glottal source: 2x oversampled wavetable oscillator + 49-tap FIR (TRMWavetable.m:117-195)
+    // glottal source: 2x oversampled wavetable oscillator (TRMWavetable.m:117-195)
     float wa, wb;   // the two oversampled table reads of this sample
     {
         double inc = (T.f0 * 0.5) * C.basicIncrement;
-        double pos1 = L.oscPos + inc;
+        double pos1 = S.oscPos + inc;
         pos1 = pos1 > 511.0 ? pos1 - 512.0 : pos1;          // mod0(), :28-34
         double pos2 = pos1 + inc;
         pos2 = pos2 > 511.0 ? pos2 - 512.0 : pos2;
-        L.oscPos = pos2;
+        S.oscPos = pos2;
         int lo1 = (int)pos1, lo2 = (int)pos2;
         float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
         int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
@@ -289,16 +218,16 @@ TRM_HD float lane_sample(Lane &L, Track &T, const Const &C, int j, float lpNoise
         wa = fma_f(fr1, a1 - a0, a0);
         wb = fma_f(fr2, b1 - b0, b0);
     }
-    // FIR in transposed form: y[m] = sum c[2k] b[m-k] + c[2k+1] a[m-k]  (TRMFIRFilter.m:116-146)
+    // 49-tap FIR, decimate by 2, transposed form: y[m] = sum c[2k] b[m-k] + c[2k+1] a[m-k]
+    // (TRMFIRFilter.m:116-146); the partial sums shift for free through the FMA destination.
     float pulse;
     {
         auto c = [&](int i) { return C.fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };
-        pulse = fma_f(c(0), wb, fma_f(c(1), wa, L.fir[0]));
-        for (int q = 0; q < 23; q++) L.fir[q] = fma_f(c(2 * q + 2), wb, fma_f(c(2 * q + 3), wa, L.fir[q + 1]));
-        L.fir[23] = c(48) * wb;
+        pulse = fma_f(c(0), wb, fma_f(c(1), wa, S.fir[0]));
+        for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), wb, fma_f(c(2 * q + 3), wa, S.fir[q + 1]));
+        S.fir[23] = c(48) * wb;
     }
-
-    // ---- source mixing (:315-333)
+    // source mixing (:315-333)
     float pulsedNoise = lpNoise * pulse;
     pulse = ax * fma_f(pulsedNoise, C.breath, pulse * (1.0f - C.breath));
     float sig;
@@ -308,14 +237,144 @@ TRM_HD float lane_sample(Lane &L, Track &T, const Const &C, int j, float lpNoise
         sig = fma_f(pulsedNoise, cm, lpNoise * (1.0f - cm));
     } else
         sig = lpNoise;
+    Excitation E;
+    E.gin = fma_f(ah1, sig, pulse) * kVtScale;
+    E.sig = sig;
+    E.thr = pulse * kVtScale;
+    // advance the fp64 tracks (:351)
+    T.glotDb += T.glotDbDelta;
+    T.axGeo *= T.axRatio;
+    T.f0 *= T.f0Ratio;
+    return E;
+}
 
-    // ---- frication band-pass (TRMFilters.m:19-29), evaluated before the tract (:336-337)
-    float fric = 2.0f * fma_f(bpAlpha, sig - L.bpX2, fma_f(bpGamma, L.bpY1, -(bpBeta * L.bpY2)));
-    L.bpX2 = L.bpX1; L.bpX1 = sig; L.bpY2 = L.bpY1; L.bpY1 = fric;
+// ================================================================ stage 2: coefficients
+struct CoefTrack {
+    double fricPos, fricPosDelta;
+    // fp32 base + delta: fricVol, fricCF, fricBW, r1..r8, velum
+    float base[12], delta[12];
+};
 
-    // ---- waveguide (:778-853): all new values from old values only
+struct Coefs {
+    float k[8];                 // C1..C8                                   (:712-726)
+    float onePlusK8;            // 1 + C8 without cancellation              (:835)
+    float alphaLR, alphaU;      // three-way junction                       (:730-736)
+    float nk1;                  // NC1                                      (:738-743)
+    float tap[8];               // frication taps FC1..FC8                  (:748-773)
+    float bpAlpha, bpBeta, bpGamma;   // frication band-pass                (TRMFilters.m:9-17)
+    float pad_;                 // 24 floats = six 16-byte groups
+};
+constexpr int kCoefFloats = 24;
+
+// frame columns: 3 fricVol, 4 fricPos, 5 fricCF, 6 fricBW, 7..14 radii, 15 velum
+TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, const float *cur)
+{
+    T.fricPos = (double)prev[4];
+    T.fricPosDelta = ((double)cur[4] - T.fricPos) / (double)C.controlPeriod;
+    const int col[12] = {3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+    for (int i = 0; i < 12; i++) {
+        T.base[i] = prev[col[i]];
+        T.delta[i] = (cur[col[i]] - prev[col[i]]) * C.invControlPeriod;
+    }
+}
+
+TRM_HD Coefs coef_sample(CoefTrack &T, const Const &C, int j)
+{
+    Coefs K;
+    const float fj = (float)j;
+    // control-rate interpolation (:676-688 evaluated as base + j*delta)
+    float fricDb = fma_f(fj, T.delta[0], T.base[0]);
+    float fricCF = fma_f(fj, T.delta[1], T.base[1]);
+    float fricBW = fma_f(fj, T.delta[2], T.base[2]);
+    float r2[8];
+    for (int i = 0; i < 8; i++) {
+        float r = fma_f(fj, T.delta[3 + i], T.base[3 + i]);
+        r2[i] = r * r;
+    }
+    float velum = fma_f(fj, T.delta[11], T.base[11]);
+
+    // scattering coefficients (:712-744)
+    for (int i = 0; i < 7; i++) K.k[i] = (r2[i] - r2[i + 1]) * rcp_f(r2[i] + r2[i + 1]);
+    float rk8 = rcp_f(r2[7] + C.apScaleSq);
+    K.k[7] = (r2[7] - C.apScaleSq) * rk8;
+    K.onePlusK8 = (r2[7] + r2[7]) * rk8;         // 1 + C8 without the cancellation of a nearly closed mouth
+    float v2 = velum * velum;
+    float jsum = 2.0f * rcp_f(r2[3] + r2[3] + v2);
+    K.alphaLR = jsum * r2[3];
+    K.alphaU = jsum * v2;
+    K.nk1 = (v2 - C.noseR1sq) * rcp_f(v2 + C.noseR1sq);
+
+    // frication taps (:748-773)
+    float fricAmp = amplitude_f(fricDb);
+    int ip = (int)T.fricPos;
+    float comp = (float)(T.fricPos - (double)ip);
+    float tapA = (1.0f - comp) * fricAmp;       // tap[ip]
+    float tapB = comp * fricAmp;                // tap[ip+1] when ip+1 < 8
+    K.tap[0] = ip == 0 ? tapA : 0.0f;
+    for (int i = 1; i < 8; i++) {
+        float t = i == ip ? tapA : 0.0f;
+        K.tap[i] = i - 1 == ip ? tapB : t;
+    }
+
+    // band-pass coefficients (TRMFilters.m:9-17): tan(pi*BW/SR), cos(2*pi*CF/SR)
+    {
+        float v = fricBW * C.invSampleRate;
+        v = v - rint_f(v);                      // tan has period 1 in v
+        float a = fabsf(v);
+        bool hi = a > 0.25f;
+        float y = 3.14159265358979f * (hi ? 0.5f - a : a);
+        float s = sin_q(y), c = cos_q(y);
+        float num = hi ? c : s, den = hi ? s : c;     // tan = num/den
+        num = v < 0.0f ? -num : num;
+        K.bpBeta = (den - num) * rcp_f(2.0f * (den + num));   // (1-t)/(2(1+t))
+        float u = fricCF * C.invSampleRate;
+        u = fabsf(u - rint_f(u));               // [0, .5]
+        bool neg = u > 0.25f;
+        u = neg ? 0.5f - u : u;                 // [0, .25]: angle in [0, pi/2]
+        bool swap = u > 0.125f;
+        float yy = 6.28318530717959f * (swap ? 0.25f - u : u);
+        float cv = swap ? sin_q(yy) : cos_q(yy);
+        cv = neg ? -cv : cv;
+        K.bpGamma = (0.5f + K.bpBeta) * cv;
+        K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
+    }
+    K.pad_ = 0.0f;
+    T.fricPos += T.fricPosDelta;                // (:351)
+    return K;
+}
+
+// ================================================================ stage 3: the tube recurrences
+struct TubeState {
+    // waveguide: travelling-wave values of the previous sample (TRMTubeModel.m:161-165)
+    wg_t oT[10], oB[10];        // oropharynx top / bottom
+    wg_t nT[6], nB[6];          // nasal
+    wg_t mReflY, mRadX, mRadY;  // mouth filter memories
+    wg_t nReflY, nRadX, nRadY;  // nose filter memories
+    wg_t throatY;
+    float bpX1, bpX2, bpY1, bpY2;   // frication band-pass memory (TRMFilters.m:19-29)
+};
+
+TRM_HD void tube_reset(TubeState &L)
+{
+    for (int i = 0; i < 10; i++) { L.oT[i] = 0.f; L.oB[i] = 0.f; }
+    for (int i = 0; i < 6; i++) { L.nT[i] = 0.f; L.nB[i] = 0.f; }
+    L.mReflY = L.mRadX = L.mRadY = 0.f;
+    L.nReflY = L.nRadX = L.nRadY = 0.f;
+    L.throatY = 0.f;
+    L.bpX1 = L.bpX2 = L.bpY1 = L.bpY2 = 0.f;
+}
+
+// Returns the tube-rate output sample (what the reference hands to -dataFill:, :346).
+TRM_HD float tube_sample(TubeState &L, const Const &C, const Excitation &E, const Coefs &K)
+{
+    // frication band-pass (TRMFilters.m:19-29), evaluated before the tract (:336-337)
+    float fric = 2.0f * fma_f(K.bpAlpha, E.sig - L.bpX2, fma_f(K.bpGamma, L.bpY1, -(K.bpBeta * L.bpY2)));
+    L.bpX2 = L.bpX1; L.bpX1 = E.sig; L.bpY2 = L.bpY1; L.bpY1 = fric;
+
+    // waveguide (:778-853): all new values from old values only
+    const float *k = K.k, *tap = K.tap;
     const wg_t d = C.damping;
-    const wg_t input = fma_f(ah1, sig, pulse) * kVtScale;
+    const wg_t input = E.gin;
     const wg_t fr = fric;
     wg_t nOT[10], nOB[10], nNT[6], nNB[6];
     nOT[0] = L.oB[0] * d + input;
@@ -330,7 +389,7 @@ TRM_HD float lane_sample(Lane &L, Track &T, const Const &C, int j, float lpNoise
         nOB[i] = (L.oB[i + 1] + dl) * d;
     }
     {
-        wg_t jp = alphaLR * L.oT[3] + (alphaLR * L.oB[4] + alphaU * L.nB[0]);
+        wg_t jp = K.alphaLR * L.oT[3] + (K.alphaLR * L.oB[4] + K.alphaU * L.nB[0]);
         nOB[3] = (jp - L.oT[3]) * d;
         nOT[4] = (jp - L.oB[4]) * d + tap[2] * fr;
         nNT[0] = (jp - L.nB[0]) * d;
@@ -348,48 +407,54 @@ TRM_HD float lane_sample(Lane &L, Track &T, const Const &C, int j, float lpNoise
         nOB[i] = (L.oB[i + 1] + dl) * d;
     }
     wg_t out;
-    {
-        wg_t refl = C.mA10 * (k[7] * L.oT[9]) - C.mB11 * L.mReflY;              // TRMFilters.m:47-52
+    {   // mouth: reflection y = a10*x - b11*y1, radiation y = a20*x + a21*x1 - b21*y1 (TRMFilters.m:47-60)
+        wg_t refl = C.mA10 * (k[7] * L.oT[9]) + C.mCoeff * L.mReflY;
         L.mReflY = refl;
         nOB[9] = d * refl;
-        wg_t rin = onePlusK8 * L.oT[9];
-        wg_t rad = C.mA20 * rin + (C.mA21 * L.mRadX - C.mB21 * L.mRadY);        // :54-60
+        wg_t rin = K.onePlusK8 * L.oT[9];
+        wg_t rad = C.mCoeff * (rin - L.mRadX + L.mRadY);
         L.mRadX = rin; L.mRadY = rad;
         out = rad;
     }
     {
-        float kk[5] = {nk1, C.nasalK[0], C.nasalK[1], C.nasalK[2], C.nasalK[3]};
+        float kk[5] = {K.nk1, C.nasalK[0], C.nasalK[1], C.nasalK[2], C.nasalK[3]};
         for (int i = 0; i < 5; i++) {
             wg_t dl = kk[i] * (L.nT[i] - L.nB[i + 1]);
             nNT[i + 1] = (L.nT[i] + dl) * d;
             nNB[i] = (L.nB[i + 1] + dl) * d;
         }
-        wg_t refl = C.nA10 * (C.nasalK[4] * L.nT[5]) - C.nB11 * L.nReflY;
+        wg_t refl = C.nA10 * (C.nasalK[4] * L.nT[5]) + C.nCoeff * L.nReflY;
         L.nReflY = refl;
         nNB[5] = d * refl;
         wg_t rin = C.onePlusNK6 * L.nT[5];
-        wg_t rad = C.nA20 * rin + (C.nA21 * L.nRadX - C.nB21 * L.nRadY);
+        wg_t rad = C.nCoeff * (rin - L.nRadX + L.nRadY);
         L.nRadX = rin; L.nRadY = rad;
         out += rad;
     }
     for (int i = 0; i < 10; i++) { L.oT[i] = nOT[i]; L.oB[i] = nOB[i]; }
     for (int i = 0; i < 6; i++) { L.nT[i] = nNT[i]; L.nB[i] = nNB[i]; }
 
-    // ---- throat (:341, TRMFilters.m:72-77)
-    wg_t ty = C.ta0 * (pulse * kVtScale) + C.tb1 * L.throatY;
+    // throat (:341, TRMFilters.m:72-77)
+    wg_t ty = C.ta0 * E.thr + C.tb1 * L.throatY;
     L.throatY = ty;
     out = ty * C.throatGain + out;
-
-    // ---- advance the fp64 tracks (:351)
-    T.glotDb += T.glotDbDelta;
-    T.axGeo *= T.axRatio;
-    T.f0 *= T.f0Ratio;
-    T.fricPos += T.fricPosDelta;
     return (float)out;
 }
 
+// ================================================================ stage 4: sample-rate conversion
+struct SrcState {
+    float src[kSrcWindow];      // last 26 tube-rate samples, src[25] newest
+    float maxAbs;
+};
+
+TRM_HD void src_reset(SrcState &L)
+{
+    for (int i = 0; i < kSrcWindow; i++) L.src[i] = 0.f;
+    L.maxAbs = 0.f;
+}
+
 // Push one tube-rate sample into the converter window (TRMRingBuffer.m:47-60, window form).
-TRM_HD void src_push(Lane &L, float s)
+TRM_HD void src_push(SrcState &L, float s)
 {
     for (int i = 0; i < kSrcWindow - 1; i++) L.src[i] = L.src[i + 1];
     L.src[kSrcWindow - 1] = s;
@@ -397,7 +462,7 @@ TRM_HD void src_push(Lane &L, float s)
 
 // One up-sampled output (TRMSampleRateConverter.m:171-233): 13 left + 13 right taps.
 // cl/cr = coefficient rows for the left wing (phase f) and right wing (phase ~f).
-TRM_HD float src_emit_up(const Lane &L, const float *cl, const float *cr)
+TRM_HD float src_emit_up(const SrcState &L, const float *cl, const float *cr)
 {
     float acc = 0.0f;
     for (int i = 0; i < kSrcWing; i++) acc = fma_f(L.src[12 - i], cl[i], acc);

@@ -222,11 +222,9 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     c.apScaleSq = (float)(p.apScale * p.apScale);
     {
         double coeff = (nyquist - p.mouthCoef) / nyquist;                // :222, TRMFilters.m:34-45
-        c.mB11 = (float)-coeff; c.mA10 = (float)(1.0 - fabs(-coeff));
-        c.mA20 = (float)coeff; c.mA21 = c.mB21 = (float)-coeff;
+        c.mCoeff = (float)coeff; c.mA10 = (float)(1.0 - fabs(-coeff));
         coeff = (nyquist - p.noseCoef) / nyquist;                        // :225
-        c.nB11 = (float)-coeff; c.nA10 = (float)(1.0 - fabs(-coeff));
-        c.nA20 = (float)coeff; c.nA21 = c.nB21 = (float)-coeff;
+        c.nCoeff = (float)coeff; c.nA10 = (float)(1.0 - fabs(-coeff));
     }
     {
         double ta0 = (p.throatCutoff * 2.0) / d.sampleRate;              // :238
@@ -244,7 +242,6 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     c.phaseIncrement = d.phaseIncrement;
     c.padSize = d.padSize;
     c.upsample = d.sampleRateRatio >= 1.0;
-    c.sampleRateRatio = (float)d.sampleRateRatio;
     c.sampleRateRatioD = d.sampleRateRatio;
     if (c.tableDiv1 < 0 || c.tableDiv2 > 512 || c.tableDiv1 > c.tableDiv2) return TRM_ERANGE;
     return TRM_OK;

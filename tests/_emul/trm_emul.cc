@@ -1,7 +1,7 @@
 // trm_emul.cc -- TEST INFRASTRUCTURE.  Runs gnuspeech_amd/csrc/trm_lane.h (the exact per-lane
-// arithmetic the HIP kernel executes) serially on the host, one voice at a time, so the fp32/fp64
-// precision plan can be checked against the oracle in a container without a GPU.  Never linked
-// into libtrm_hip.so and never used by the product path.
+// stage arithmetic the HIP kernel executes) serially on the host, one voice at a time, so the
+// fp32/fp64 precision plan can be checked against the oracle in a container without a GPU.  Never
+// linked into libtrm_hip.so and never used by the product path.
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,19 +36,19 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
             x1 = nz;
         }
     }
-    Lane L; Track T;
-    lane_reset(L);
+    ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS; SrcState SS;
+    excite_reset(ES); tube_reset(TS); src_reset(SS);
     uint32_t t = 0; uint64_t e = 0, n = 0, k = 0;
     auto sineLookup = [&](int i) { return sine[i]; };
     auto push = [&](float s) {
-        src_push(L, s);
+        src_push(SS, s);
         while (e <= n) {
             uint32_t f = t & 0xFFFF;
-            float y = src_emit_up(L, &rows[(size_t)f * kSrcRow], &rows[(size_t)(0xFFFF - f) * kSrcRow]);
+            float y = src_emit_up(SS, &rows[(size_t)f * kSrcRow], &rows[(size_t)(0xFFFF - f) * kSrcRow]);
             if (k < cap) out[k] = y;
             k++;
             float a = fabsf(y);
-            if (a > L.maxAbs) L.maxAbs = a;
+            if (a > SS.maxAbs) SS.maxAbs = a;
             t += C.timeRegisterIncrement;
             e += t >> 16;
             t &= 0xFFFF;
@@ -56,15 +56,18 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
         n++;
     };
     for (size_t f = 1; f < nframes; f++) {
-        track_setup(T, C, frames + 16 * (f - 1), frames + 16 * f);
+        excite_track_setup(ET, C, frames + 16 * (f - 1), frames + 16 * f);
+        coef_track_setup(CT, C, frames + 16 * (f - 1), frames + 16 * f);
         for (int j = 0; j < C.controlPeriod; j++) {
-            float s = lane_sample(L, T, C, j, lp[n], sineLookup);
+            Excitation E = excite_sample(ES, ET, C, j, lp[n], sineLookup);
+            Coefs K = coef_sample(CT, C, j);
+            float s = tube_sample(TS, C, E, K);
             if (tube) tube[n] = s;
             push(s);
         }
     }
     for (int i = 0; i < 2 * C.padSize; i++) push(0.0f);
     *nout = (uint32_t)k;
-    *maxv = L.maxAbs;
+    *maxv = SS.maxAbs;
     return TRM_OK;
 }
