@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrm_hip.so")
+# TRM_LIB selects a diagnostic build (tools/stage_profile.py); the product is libtrm_hip.so
+LIB_PATH = os.environ.get("TRM_LIB") or os.path.join(_HERE, "libtrm_hip.so")
 
 TRM_OK = 0
 (TRM_EINVAL, TRM_EINVAL_LENGTH, TRM_EFIR, TRM_ENOMEM, TRM_EHIP, TRM_ENODEVICE, TRM_EIO, TRM_EPARSE,

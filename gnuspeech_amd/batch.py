@@ -24,7 +24,10 @@ class TRMBatch:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().trm_batch_destroy(h)
+            try:
+                lib().trm_batch_destroy(h)
+            except Exception:      # interpreter shutdown: the process is going away anyway
+                pass
             self._h = None
 
     def samples_for_frames(self, nframes):

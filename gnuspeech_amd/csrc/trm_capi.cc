@@ -22,6 +22,9 @@
 namespace {
 
 thread_local std::string g_err;
+#ifdef TRM_STAMP
+unsigned long long *g_stampPtr = nullptr;
+#endif
 
 int fail(int code, const char *fmt, ...)
 {
@@ -253,6 +256,17 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     a.src_rows = b->dRows;
     a.sine = b->dSine;
     a.nvoices = (uint32_t)nvoices;
+    a.stamps = nullptr;
+#ifdef TRM_STAMP
+    {   // diagnostic library only: per-workgroup, per-role {work, wait} cycle sums; read back with
+        // trm_batch_noise_table-like copy in tools/stage_profile.py via TRM_STAMP_PTR
+        static unsigned long long *dStamps = nullptr;
+        if (!dStamps) HIP_TRY(hipMalloc((void **)&dStamps, 65536 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(dStamps, 0, 65536 * 8 * sizeof(unsigned long long), stream));
+        a.stamps = dStamps;
+        g_stampPtr = dStamps;
+    }
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (b->timing) {
         HIP_TRY(hipEventCreate(&e0));
@@ -286,6 +300,15 @@ int trm_batch_kernel_time_ms(trm_batch *b, double *total_ms, uint32_t *launches)
     *launches = n;
     return TRM_OK;
 }
+
+#ifdef TRM_STAMP
+extern "C" int trm_debug_stamps(unsigned long long *host_out, size_t n)
+{
+    if (!g_stampPtr) return TRM_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return TRM_EHIP;
+    return hipMemcpy(host_out, g_stampPtr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? TRM_OK : TRM_EHIP;
+}
+#endif
 
 int trm_batch_noise_table(trm_batch *b, float *host_out, size_t n)
 {

@@ -26,6 +26,7 @@ struct TubeArgs {
     const float *src_rows;
     const float *sine;
     uint32_t nvoices;
+    unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product
 };
 
 struct ScaleArgs {

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "trm_kernels.h"
 #include "trm_lane.h"
 
@@ -20,7 +22,7 @@ constexpr int kWave = 64;
 constexpr int kRoles = 4;            // waves per workgroup: excite, coef, tube, convert
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
 constexpr int kTile = 32;            // outputs staged per lane before a flush (128-byte rows)
-constexpr int kTileStride = kTile + 1;   // odd stride: conflict-free column writes and row reads
+constexpr int kTileStride = kTile + 4;   // 16-byte aligned rows for b128 row reads (column writes 4-way, 1 per output)
 constexpr int kRowSlots = 64;        // converter coefficient ring: one slot per output sample
 constexpr int kRowHalf = 32;         //   refilled by halves, one half ahead
 constexpr int kSlotFloats = 32;      //   slot = left-wing row (16 floats) + right-wing row (16 floats)
@@ -72,6 +74,26 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// Diagnostic build only (-DTRM_STAMP, tools/stage_profile.py): per-role cycles spent working vs
+// waiting at the step barrier.  In the product build these macros expand to nothing.
+#ifdef TRM_STAMP
+#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0;
+#define STAMP_BEGIN st_t0 = __builtin_readcyclecounter();
+#define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0;
+#define STAMP_END st_wait += __builtin_readcyclecounter() - st_t1;
+#define STAMP_STORE(role_)                                                          \
+    if (lane == 0 && A.stamps) {                                                    \
+        A.stamps[(blockIdx.x * kRoles + (role_)) * 2] = st_work;                    \
+        A.stamps[(blockIdx.x * kRoles + (role_)) * 2 + 1] = st_wait;                \
+    }
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN
+#define STAMP_MID
+#define STAMP_END
+#define STAMP_STORE(role_)
+#endif
+
 __device__ __forceinline__ void load_frame(const float *frames, uint32_t fi, float *dst, int quads)
 {
     const float4 *p = reinterpret_cast<const float4 *>(frames + (size_t)fi * 16);
@@ -92,6 +114,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     __shared__ float sY[2 * kTB * kWave];                                        // tube-rate samples
     __shared__ float sStage[kWave * kTileStride];                                // convert: output tile
     __shared__ __attribute__((aligned(16))) float sRows[kRowSlots * kSlotFloats]; // convert: coefficient ring
+    __shared__ float *sOutPtr[kWave];                                            // convert: row destinations
+    __shared__ uint32_t sOutLen[kWave];                                          // convert: row lengths
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
     __shared__ float sSine[kTableLen];                                           // excite: sine table
 
@@ -132,7 +156,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             dma_wait_all();
         }
         uint32_t j = CP, f = 0;
+        STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
             const int buf = step & 1;
             for (int u = 0; u < kTB; u++) {
                 const uint32_t n = step * kTB + u;
@@ -154,8 +180,11 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                     sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
                 }
             }
+            STAMP_MID
             __syncthreads();
+            STAMP_END
         }
+        STAMP_STORE(role)
         dma_wait_all();   // nothing may still be writing LDS when the wave ends
     } else if (role == 1) {
         // ------------------------------------------------------------ coef
@@ -163,7 +192,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         float cur[16], prev[16];
         if (nSteps > 0) load_frame(frames, 0, cur, 4);
         uint32_t j = CP, f = 0;
+        STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
             const int buf = step & 1;
             for (int u = 0; u < kTB; u++) {
                 const uint32_t n = step * kTB + u;
@@ -186,13 +217,18 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                     dst[5 * kWave] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
                 }
             }
+            STAMP_MID
             __syncthreads();
+            STAMP_END
         }
+        STAMP_STORE(role)
     } else if (role == 2) {
         // ------------------------------------------------------------ tube
         TubeState S;
         tube_reset(S);
+        STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
             if (step >= 1) {
                 const uint32_t blk = step - 1;
                 const int buf = blk & 1;
@@ -216,8 +252,11 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                     }
                 }
             }
+            STAMP_MID
             __syncthreads();
+            STAMP_END
         }
+        STAMP_STORE(role)
     } else {
         // ------------------------------------------------------------ convert
         float *const outBase = A.out + A.out_offset[v];
@@ -229,7 +268,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
         }
         if (!laneValid) noutLane = 0;
-        SrcState S;
+        sOutPtr[lane] = outBase;         // read back row-wise by the tile flush (this wave only)
+        sOutLen[lane] = noutLane;
+        SrcState<kTB> S;
         src_reset(S);
         // Converter coefficients for output k live in slot k & 63.  Output k's phase is (k*inc) mod 2^16
         // (TRMSampleRateConverter.m:221-232), so rows can be fetched ahead by output index alone.
@@ -243,70 +284,95 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                       &sRows[(half * kRowHalf + jj * 8) * kSlotFloats]);
             }
         };
+        float cl[16], cr[16];            // coefficient rows of the NEXT output to emit (software prefetch)
+        auto load_rows = [&](uint32_t k) {
+            const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(k & (kRowSlots - 1)) * kSlotFloats]);
+            for (int q = 0; q < 4; q++) {
+                float4 a = rp[q], b = rp[4 + q];
+                cl[4 * q] = a.x; cl[4 * q + 1] = a.y; cl[4 * q + 2] = a.z; cl[4 * q + 3] = a.w;
+                cr[4 * q] = b.x; cr[4 * q + 1] = b.y; cr[4 * q + 2] = b.z; cr[4 * q + 3] = b.w;
+            }
+        };
         if (nSteps > 0) {
             fill_rows_half(0, 0);
             fill_rows_half(kRowHalf, 1);
             dma_wait_all();
+            load_rows(0);
         }
         uint32_t e = 0;          // converter read position, in pushed samples (uniform)
         uint32_t t = 0;          // 16.16 time register, N part cleared (uniform)
         uint32_t kout = 0;       // outputs emitted (uniform)
         uint32_t tilePos = 0;    // outputs staged in LDS (uniform)
+
+        auto flush_tile = [&]() {
+            // 8 rows per pass: lane -> row (lane>>3), 16-byte piece (lane&7); a row is 128 contiguous bytes
+            const uint32_t kbase = kout - tilePos;
+            const uint32_t c4 = (uint32_t)(lane & 7) * 4u;
+#pragma unroll 4
+            for (int it = 0; it < kWave / 8; it++) {
+                const int row = it * 8 + (lane >> 3);
+                float *dst = sOutPtr[row];
+                const uint32_t nr = sOutLen[row];
+                const float4 val = *reinterpret_cast<const float4 *>(&sStage[row * kTileStride + c4]);
+                const uint32_t k = kbase + c4;
+                const uint32_t lim = nr < kbase + tilePos ? nr : kbase + tilePos;   // valid outputs end
+                if (k + 3 < lim) {
+                    float *p = dst + k;
+                    p[0] = val.x; p[1] = val.y; p[2] = val.z; p[3] = val.w;
+                } else {
+                    if (k < lim) dst[k] = val.x;
+                    if (k + 1 < lim) dst[k + 1] = val.y;
+                    if (k + 2 < lim) dst[k + 2] = val.z;
+                }
+            }
+            tilePos = 0;
+        };
+
+        auto emit_for = [&](uint32_t n, auto uTag) {
+            constexpr int U = decltype(uTag)::value;
+            while (e <= n) {     // TRMSampleRateConverter.m:171-233, uniform trip count
+                float y = src_emit_up<kTB, U>(S, cl, cr);
+                const uint32_t k = kout;
+                kout++;
+                t += inc;
+                e += t >> 16;
+                t &= 0xFFFFu;
+                if ((kout & (kRowHalf - 1)) == 0) {
+                    // entering a ring half: it was requested one half ago; refill the half just left
+                    dma_wait_all();
+                    fill_rows_half(kout + kRowHalf, ((kout / kRowHalf) + 1) & 1);
+                }
+                load_rows(kout);                 // prefetch the next output's coefficients
+                float a = fabsf(y);
+                S.maxAbs = (k < noutLane && a > S.maxAbs) ? a : S.maxAbs;
+                sStage[lane * kTileStride + tilePos] = y;
+                tilePos++;
+                if (tilePos == kTile) flush_tile();
+            }
+        };
+
+        STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
             if (step >= 2) {
                 const uint32_t blk = step - 2;
                 const int buf = blk & 1;
+                float sv[kTB];
                 for (int u = 0; u < kTB; u++) {
                     const uint32_t n = blk * kTB + u;
-                    if (n < nTotal) {
-                        float s = sY[(buf * kTB + u) * kWave + lane];
-                        s = n < ntubeLane ? s : 0.0f;
-                        src_push(S, s);
-                        while (e <= n) {     // TRMSampleRateConverter.m:171-233, uniform trip count
-                            if ((kout & (kRowHalf - 1)) == 0 && kout > 0) {
-                                dma_wait_all();
-                                fill_rows_half(kout + kRowHalf, ((kout / kRowHalf) + 1) & 1);
-                            }
-                            const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(kout & (kRowSlots - 1)) * kSlotFloats]);
-                            float cl[16], cr[16];
-                            for (int q = 0; q < 4; q++) {
-                                float4 a = rp[q], b = rp[4 + q];
-                                cl[4 * q] = a.x; cl[4 * q + 1] = a.y; cl[4 * q + 2] = a.z; cl[4 * q + 3] = a.w;
-                                cr[4 * q] = b.x; cr[4 * q + 1] = b.y; cr[4 * q + 2] = b.z; cr[4 * q + 3] = b.w;
-                            }
-                            float y = src_emit_up(S, cl, cr);
-                            float a = fabsf(y);
-                            S.maxAbs = (kout < noutLane && a > S.maxAbs) ? a : S.maxAbs;
-                            sStage[lane * kTileStride + tilePos] = y;
-                            tilePos++;
-                            kout++;
-                            t += inc;
-                            e += t >> 16;
-                            t &= 0xFFFFu;
-                            if (tilePos == kTile || (e > n && n + 1 == nTotal)) {
-                                // flush the staged tile: row r = voice of lane r, contiguous per row
-                                const uint32_t kbase = kout - tilePos;
-#pragma unroll 1
-                                for (int r = 0; r < kWave; r += 2) {
-                                    // lanes 0..31 write row r, lanes 32..63 write row r+1
-                                    const int rr = r + (lane >> 5);
-                                    uint32_t lo = __shfl((uint32_t)(uintptr_t)outBase, rr, kWave);
-                                    uint32_t hi = __shfl((uint32_t)((uintptr_t)outBase >> 32), rr, kWave);
-                                    uint32_t nr = __shfl(noutLane, rr, kWave);
-                                    float *dst = reinterpret_cast<float *>(((uintptr_t)hi << 32) | lo);
-                                    const uint32_t col = (uint32_t)(lane & 31);
-                                    float val = sStage[rr * kTileStride + col];
-                                    uint32_t k = kbase + col;
-                                    if (col < tilePos && k < nr) dst[k] = val;
-                                }
-                                tilePos = 0;
-                            }
-                        }
-                    }
+                    float s = sY[(buf * kTB + u) * kWave + lane];
+                    sv[u] = (n < ntubeLane && n < nTotal) ? s : 0.0f;
                 }
+                src_push_block<kTB>(S, sv);
+                if (blk * kTB + 0 < nTotal) emit_for(blk * kTB + 0, std::integral_constant<int, 0>());
+                if (blk * kTB + 1 < nTotal) emit_for(blk * kTB + 1, std::integral_constant<int, 1>());
             }
+            STAMP_MID
             __syncthreads();
+            STAMP_END
         }
+        STAMP_STORE(role)
+        if (tilePos > 0) flush_tile();
         dma_wait_all();
         if (laneValid) {
             A.number_samples[vRaw] = noutLane;

@@ -442,32 +442,47 @@ TRM_HD float tube_sample(TubeState &L, const Const &C, const Excitation &E, cons
 }
 
 // ================================================================ stage 4: sample-rate conversion
+// The converter keeps the last 26 tube-rate samples per lane (TRMRingBuffer.m:47-60 as a sliding
+// window).  The window array holds kSrcWindow + B - 1 samples so that a block of B pushes costs one
+// shift by B; sample u of the block sees src[u .. u+25].
+template <int B>
 struct SrcState {
-    float src[kSrcWindow];      // last 26 tube-rate samples, src[25] newest
+    float src[kSrcWindow + B - 1];
     float maxAbs;
 };
 
-TRM_HD void src_reset(SrcState &L)
+template <int B>
+TRM_HD void src_reset(SrcState<B> &L)
 {
-    for (int i = 0; i < kSrcWindow; i++) L.src[i] = 0.f;
+    for (int i = 0; i < kSrcWindow + B - 1; i++) L.src[i] = 0.f;
     L.maxAbs = 0.f;
 }
 
-// Push one tube-rate sample into the converter window (TRMRingBuffer.m:47-60, window form).
-TRM_HD void src_push(SrcState &L, float s)
+// Shift the window by B and append the block's B new samples.
+template <int B>
+TRM_HD void src_push_block(SrcState<B> &L, const float *s)
 {
-    for (int i = 0; i < kSrcWindow - 1; i++) L.src[i] = L.src[i + 1];
-    L.src[kSrcWindow - 1] = s;
+    for (int i = 0; i < kSrcWindow - 1; i++) L.src[i] = L.src[i + B];
+    for (int u = 0; u < B; u++) L.src[kSrcWindow - 1 + u] = s[u];
 }
 
-// One up-sampled output (TRMSampleRateConverter.m:171-233): 13 left + 13 right taps.
-// cl/cr = coefficient rows for the left wing (phase f) and right wing (phase ~f).
-TRM_HD float src_emit_up(const SrcState &L, const float *cl, const float *cr)
+// One up-sampled output (TRMSampleRateConverter.m:171-233): 13 left + 13 right taps around the
+// window of block sample U.  cl/cr = coefficient rows for the left wing (phase f) and right wing
+// (phase ~f).  Four independent partial sums keep the FMA pipeline busy.
+template <int B, int U>
+TRM_HD float src_emit_up(const SrcState<B> &L, const float *cl, const float *cr)
 {
-    float acc = 0.0f;
-    for (int i = 0; i < kSrcWing; i++) acc = fma_f(L.src[12 - i], cl[i], acc);
-    for (int i = 0; i < kSrcWing; i++) acc = fma_f(L.src[13 + i], cr[i], acc);
-    return acc;
+    const float *w = L.src + U;
+    float a0 = w[12] * cl[0], a1 = w[11] * cl[1], a2 = w[13] * cr[0], a3 = w[14] * cr[1];
+    for (int i = 2; i < kSrcWing - 1; i += 2) {
+        a0 = fma_f(w[12 - i], cl[i], a0);
+        a1 = fma_f(w[11 - i], cl[i + 1], a1);
+        a2 = fma_f(w[13 + i], cr[i], a2);
+        a3 = fma_f(w[14 + i], cr[i + 1], a3);
+    }
+    a0 = fma_f(w[0], cl[12], a0);
+    a2 = fma_f(w[25], cr[12], a2);
+    return (a0 + a1) + (a2 + a3);
 }
 
 }  // namespace trm

@@ -131,7 +131,10 @@ class TRMTubeModel:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().trm_tube_destroy(h)
+            try:
+                lib().trm_tube_destroy(h)
+            except Exception:      # interpreter shutdown: the process is going away anyway
+                pass
             self._h = None
 
     def derived(self):

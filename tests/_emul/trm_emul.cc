@@ -36,15 +36,15 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
             x1 = nz;
         }
     }
-    ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS; SrcState SS;
+    ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS; SrcState<1> SS;
     excite_reset(ES); tube_reset(TS); src_reset(SS);
     uint32_t t = 0; uint64_t e = 0, n = 0, k = 0;
     auto sineLookup = [&](int i) { return sine[i]; };
     auto push = [&](float s) {
-        src_push(SS, s);
+        src_push_block<1>(SS, &s);
         while (e <= n) {
             uint32_t f = t & 0xFFFF;
-            float y = src_emit_up(SS, &rows[(size_t)f * kSrcRow], &rows[(size_t)(0xFFFF - f) * kSrcRow]);
+            float y = src_emit_up<1, 0>(SS, &rows[(size_t)f * kSrcRow], &rows[(size_t)(0xFFFF - f) * kSrcRow]);
             if (k < cap) out[k] = y;
             k++;
             float a = fabsf(y);

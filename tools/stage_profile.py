@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Where does a pipeline step spend its cycles?  Loads the TRM_STAMP diagnostic build
+(gnuspeech_amd/libtrm_hip_stamp.so: `make -C gnuspeech_amd/csrc stamp`) and prints, per pipeline
+role, the cycles spent working vs waiting at the step barrier (median over workgroups).
+Read the SHARES, not the run time: stamps perturb the kernel."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["TRM_LIB"] = os.path.join(ROOT, "gnuspeech_amd", "libtrm_hip_stamp.so")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import cases  # noqa: E402
+import gnuspeech_amd as g  # noqa: E402
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
+wl = sys.argv[3] if len(sys.argv) > 3 else "static"
+nframes = int(round(secs * 250)) + 1
+fr = cases.config2_frames(V, nframes=nframes) if wl == "static" else cases.config3_frames(V, nframes=nframes)
+b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params(44100.0)))
+st = b.prepare_device(fr)
+for _ in range(2):
+    b.synthesize_device(st)
+torch.cuda.synchronize()
+L = g.lib()
+nwg = (V + 63) // 64
+buf = np.zeros(nwg * 8, dtype=np.uint64)
+L.trm_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
+assert L.trm_debug_stamps(buf.ctypes.data, buf.size) == 0
+s = buf.reshape(nwg, 4, 2).astype(np.float64)
+ntube = (nframes - 1) * b.derived["controlPeriod"] + 26
+names = ["excite", "coef", "tube", "convert"]
+print("voices %d, %d tube samples; cycles per tube sample (median over %d workgroups)" % (V, ntube, nwg))
+for r in range(4):
+    w, q = np.median(s[:, r, 0]) / ntube, np.median(s[:, r, 1]) / ntube
+    print("  %-8s work %7.0f  barrier-wait %7.0f  total %7.0f" % (names[r], w, q, w + q))
