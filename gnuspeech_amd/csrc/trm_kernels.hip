@@ -16,13 +16,17 @@
 #include "trm_kernels.h"
 #include "trm_lane.h"
 
+#ifndef TRM_ABL
+#define TRM_ABL 0    // diagnostic ablations of the convert stage (tools/stage_profile.py); 0 in the product
+#endif
+
 namespace trm {
 
 constexpr int kWave = 64;
 constexpr int kRoles = 4;            // waves per workgroup: excite, coef, tube, convert
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
-constexpr int kTile = 32;            // outputs staged per lane before a flush (128-byte rows)
-constexpr int kTileStride = kTile + 4;   // 16-byte aligned rows for b128 row reads (column writes 4-way, 1 per output)
+constexpr int kTile = 16;            // outputs per staged half-tile; the staging ring holds two halves
+constexpr int kTileStride = 2 * kTile + 4;   // 16-byte aligned rows for b128 row reads
 constexpr int kRowSlots = 64;        // converter coefficient ring: one slot per output sample
 constexpr int kRowHalf = 32;         //   refilled by halves, one half ahead
 constexpr int kSlotFloats = 32;      //   slot = left-wing row (16 floats) + right-wing row (16 floats)
@@ -54,6 +58,8 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 // tracked by vmcnt; the compiler does not know these writes, so readers wait explicitly.
 typedef __attribute__((address_space(1))) const void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
+// 16-byte vector with 4-byte alignment: PCM rows start at arbitrary sample offsets
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ void dma16(const float *src, float *ldsBaseUniform)
 {
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     __shared__ float *sOutPtr[kWave];                                            // convert: row destinations
     __shared__ uint32_t sOutLen[kWave];                                          // convert: row lengths
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
+    __shared__ float sFir[32];                                                   // excite: FIR taps
     __shared__ float sSine[kTableLen];                                           // excite: sine table
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -148,6 +155,11 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         ExciteState S;
         ExciteTrack T;
         excite_reset(S);
+        // The 25 distinct FIR taps live in VGPRs of this wave (uniform values): as SGPRs they would
+        // exceed the scalar file together with the other constants and be spilled to VGPR lanes.
+        for (int i = lane; i < kFirUnique; i += kWave) sFir[i] = C.fir[i];
+        float firv[kFirUnique];
+        for (int i = 0; i < kFirUnique; i++) firv[i] = sFir[i];
         float cur[4], prev[4];
         if (nSteps > 0) {
             load_frame(frames, 0, cur, 1);
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         dma_wait_all();
                         fill_noise_half(n + kNoiseHalf, ((n / kNoiseHalf) + 1) & 1);
                     }
-                    Excitation E = excite_sample(S, T, C, (int)j, sNoise[n & (kNoiseRing - 1)], sine);
+                    Excitation E = excite_sample(S, T, C, firv, (int)j, sNoise[n & (kNoiseRing - 1)], sine);
                     j++;
                     sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
                 }
@@ -284,71 +296,80 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                       &sRows[(half * kRowHalf + jj * 8) * kSlotFloats]);
             }
         };
-        float cl[16], cr[16];            // coefficient rows of the NEXT output to emit (software prefetch)
-        auto load_rows = [&](uint32_t k) {
+        // Two coefficient register sets used alternately inside a step; set A always holds the rows of the
+        // step's first output, fetched at the end of the previous step so the LDS latency hides behind the
+        // barrier.  Inside the step the rows of output o+1 are requested before the 26 FMAs of output o.
+        float cA[32], cB[32];
+        auto load_rows = [&](float *c, uint32_t k) {
             const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(k & (kRowSlots - 1)) * kSlotFloats]);
-            for (int q = 0; q < 4; q++) {
-                float4 a = rp[q], b = rp[4 + q];
-                cl[4 * q] = a.x; cl[4 * q + 1] = a.y; cl[4 * q + 2] = a.z; cl[4 * q + 3] = a.w;
-                cr[4 * q] = b.x; cr[4 * q + 1] = b.y; cr[4 * q + 2] = b.z; cr[4 * q + 3] = b.w;
+            for (int q = 0; q < 8; q++) {
+                float4 a = rp[q];
+                c[4 * q] = a.x; c[4 * q + 1] = a.y; c[4 * q + 2] = a.z; c[4 * q + 3] = a.w;
             }
         };
         if (nSteps > 0) {
             fill_rows_half(0, 0);
             fill_rows_half(kRowHalf, 1);
             dma_wait_all();
-            load_rows(0);
+            load_rows(cA, 0);
         }
-        uint32_t e = 0;          // converter read position, in pushed samples (uniform)
-        uint32_t t = 0;          // 16.16 time register, N part cleared (uniform)
-        uint32_t kout = 0;       // outputs emitted (uniform)
-        uint32_t tilePos = 0;    // outputs staged in LDS (uniform)
+        uint32_t e = 0;           // converter read position, in pushed samples (uniform)
+        uint32_t t = 0;           // 16.16 time register, N part cleared (uniform)
+        uint32_t kout = 0;        // outputs emitted (uniform)
+        uint32_t kflushed = 0;    // outputs written to HBM (uniform, multiple of kTile)
+        uint32_t rowsHalfDone = 0;   // ring halves already re-requested (uniform)
 
-        auto flush_tile = [&]() {
-            // 8 rows per pass: lane -> row (lane>>3), 16-byte piece (lane&7); a row is 128 contiguous bytes
-            const uint32_t kbase = kout - tilePos;
-            const uint32_t c4 = (uint32_t)(lane & 7) * 4u;
-#pragma unroll 4
-            for (int it = 0; it < kWave / 8; it++) {
-                const int row = it * 8 + (lane >> 3);
-                float *dst = sOutPtr[row];
-                const uint32_t nr = sOutLen[row];
-                const float4 val = *reinterpret_cast<const float4 *>(&sStage[row * kTileStride + c4]);
-                const uint32_t k = kbase + c4;
-                const uint32_t lim = nr < kbase + tilePos ? nr : kbase + tilePos;   // valid outputs end
-                if (k + 3 < lim) {
-                    float *p = dst + k;
-                    p[0] = val.x; p[1] = val.y; p[2] = val.z; p[3] = val.w;
-                } else {
-                    if (k < lim) dst[k] = val.x;
-                    if (k + 1 < lim) dst[k + 1] = val.y;
-                    if (k + 2 < lim) dst[k + 2] = val.z;
-                }
-            }
-            tilePos = 0;
-        };
-
-        auto emit_for = [&](uint32_t n, auto uTag) {
-            constexpr int U = decltype(uTag)::value;
-            while (e <= n) {     // TRMSampleRateConverter.m:171-233, uniform trip count
-                float y = src_emit_up<kTB, U>(S, cl, cr);
-                const uint32_t k = kout;
-                kout++;
+        // outputs belonging to tube sample n: those k with floor(k*inc / 2^16) == n (uniform, scalar only)
+        auto count_outputs = [&](uint32_t n) {
+            uint32_t c = 0;
+            while (e <= n) {
                 t += inc;
                 e += t >> 16;
                 t &= 0xFFFFu;
-                if ((kout & (kRowHalf - 1)) == 0) {
-                    // entering a ring half: it was requested one half ago; refill the half just left
-                    dma_wait_all();
-                    fill_rows_half(kout + kRowHalf, ((kout / kRowHalf) + 1) & 1);
-                }
-                load_rows(kout);                 // prefetch the next output's coefficients
-                float a = fabsf(y);
-                S.maxAbs = (k < noutLane && a > S.maxAbs) ? a : S.maxAbs;
-                sStage[lane * kTileStride + tilePos] = y;
-                tilePos++;
-                if (tilePos == kTile) flush_tile();
+                c++;
             }
+            return c;
+        };
+        auto emit_one = [&](const float *cur, float *nxt, bool second) {
+#if TRM_ABL != 2
+            load_rows(nxt, kout + 1);
+#endif
+#if TRM_ABL == 3
+            float y = cur[0] + cur[16] + S.src[second ? 1 : 0];
+#else
+            float y = second ? src_emit_up<kTB, 1>(S, cur, cur + 16) : src_emit_up<kTB, 0>(S, cur, cur + 16);
+#endif
+            float a = fabsf(y);
+            S.maxAbs = (kout < noutLane && a > S.maxAbs) ? a : S.maxAbs;
+            sStage[lane * kTileStride + (kout & (2 * kTile - 1))] = y;
+            kout++;
+        };
+        // one half (kTile outputs) of the staging ring -> HBM: 16 rows per pass, lane -> row (lane>>2),
+        // 16-byte piece (lane&3); a row is 64 contiguous bytes
+        auto flush_half = [&]() {
+#if TRM_ABL == 1
+            kflushed += kTile;
+            return;
+#endif
+            const uint32_t c4 = (uint32_t)(lane & 3) * 4u;
+            const uint32_t col = (kflushed & (2 * kTile - 1)) + c4;
+            const uint32_t k = kflushed + c4;
+#pragma unroll
+            for (int it = 0; it < kWave / 16; it++) {
+                const int row = it * 16 + (lane >> 2);
+                float *dst = sOutPtr[row] + k;
+                const uint32_t lim = sOutLen[row];
+                const float4 val = *reinterpret_cast<const float4 *>(&sStage[row * kTileStride + col]);
+                if (k + 3 < lim && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                    *reinterpret_cast<float4 *>(dst) = val;
+                } else {
+                    if (k < lim) dst[0] = val.x;
+                    if (k + 1 < lim) dst[1] = val.y;
+                    if (k + 2 < lim) dst[2] = val.z;
+                    if (k + 3 < lim) dst[3] = val.w;
+                }
+            }
+            kflushed += kTile;
         };
 
         STAMP_DECL
@@ -364,15 +385,33 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                     sv[u] = (n < ntubeLane && n < nTotal) ? s : 0.0f;
                 }
                 src_push_block<kTB>(S, sv);
-                if (blk * kTB + 0 < nTotal) emit_for(blk * kTB + 0, std::integral_constant<int, 0>());
-                if (blk * kTB + 1 < nTotal) emit_for(blk * kTB + 1, std::integral_constant<int, 1>());
+                // about to read coefficient slots of the next ring half: its DMA (issued most of a half
+                // ago) must have landed
+                if (((kout + 8) / kRowHalf) > rowsHalfDone) dma_wait_all();
+                const uint32_t n0 = blk * kTB;
+                const uint32_t cnt0 = n0 < nTotal ? count_outputs(n0) : 0;
+                const uint32_t cntAll = cnt0 + (n0 + 1 < nTotal ? count_outputs(n0 + 1) : 0);
+                // straight-line emission, register sets alternate A, B, A, ... from the step's first output
+                for (uint32_t o = 0; o < cntAll; o += 2) {
+                    emit_one(cA, cB, o >= cnt0);
+                    if (o + 1 < cntAll) emit_one(cB, cA, o + 1 >= cnt0);
+                    else load_rows(cA, kout);      // odd count: the next step starts from set A again
+                }
+                // single-site housekeeping: coefficient ring refill, staged tile flush
+                if ((kout / kRowHalf) > rowsHalfDone) {
+                    // a ring half has been fully consumed: wait for the DMA issued one half ago, refill it
+                    dma_wait_all();
+                    rowsHalfDone++;
+                    fill_rows_half((rowsHalfDone + 1) * kRowHalf, (rowsHalfDone + 1) & 1);
+                }
+                if (kout - kflushed >= kTile) flush_half();
             }
             STAMP_MID
             __syncthreads();
             STAMP_END
         }
         STAMP_STORE(role)
-        if (tilePos > 0) flush_tile();
+        while (kflushed < kout) flush_half();     // tail (rows are masked by their own lengths)
         dma_wait_all();
         if (laneValid) {
             A.number_samples[vRaw] = noutLane;

@@ -180,10 +180,12 @@ TRM_HD float pulse_table(int i, const Const &C, int newDiv2, float invFall)
     return i < C.tableDiv1 ? rise : v;
 }
 
-// `j` = position in the control period (uniform), `lpNoise` = the voice-independent low-passed
-// noise sample (uniform), `sineTab` = 512-entry sine table lookup.
+// `fir` = C.fir (the caller decides where the taps live), `j` = position in the control period
+// (uniform), `lpNoise` = the voice-independent low-passed noise sample (uniform), `sineTab` = 512-entry
+// sine table lookup.
 template <class SineLookup>
-TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, int j, float lpNoise, SineLookup sineTab)
+TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, const float *fir, int j, float lpNoise,
+                                SineLookup sineTab)
 {
     // amplitude of voicing with its clamps (:294-296), in fp64: it feeds rint() below
     double axd = T.glotDb >= 60.0 ? 1.0 : T.axGeo;
@@ -222,7 +224,7 @@ TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, 
     // (TRMFIRFilter.m:116-146); the partial sums shift for free through the FMA destination.
     float pulse;
     {
-        auto c = [&](int i) { return C.fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };
+        auto c = [&](int i) { return fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };   // fir = the 25 distinct taps
         pulse = fma_f(c(0), wb, fma_f(c(1), wa, S.fir[0]));
         for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), wb, fma_f(c(2 * q + 3), wa, S.fir[q + 1]));
         S.fir[23] = c(48) * wb;

@@ -59,7 +59,7 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
         excite_track_setup(ET, C, frames + 16 * (f - 1), frames + 16 * f);
         coef_track_setup(CT, C, frames + 16 * (f - 1), frames + 16 * f);
         for (int j = 0; j < C.controlPeriod; j++) {
-            Excitation E = excite_sample(ES, ET, C, j, lp[n], sineLookup);
+            Excitation E = excite_sample(ES, ET, C, C.fir, j, lp[n], sineLookup);
             Coefs K = coef_sample(CT, C, j);
             float s = tube_sample(TS, C, E, K);
             if (tube) tube[n] = s;

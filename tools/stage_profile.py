@@ -8,7 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["TRM_LIB"] = os.path.join(ROOT, "gnuspeech_amd", "libtrm_hip_stamp.so")
+os.environ["TRM_LIB"] = os.environ.get("TRM_STAMP_LIB") or os.path.join(ROOT, "gnuspeech_amd", "libtrm_hip_stamp.so")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
