@@ -134,6 +134,8 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
         if (rc == TRM_EINVAL_LENGTH) fprintf(stderr, "Illegal tube length: %g\n", params->length);   // TRMTubeModel.m:205
         return fail(rc, "%s", trm_strerror(rc));
     }
+    if (c.controlPeriod < 4)
+        return fail(TRM_ERANGE, "control period of %d tube samples is below the kernel's pipeline step", c.controlPeriod);
     if (!c.upsample)
         return fail(TRM_ERANGE, "tube rate %d Hz above the output rate %g Hz: the down-sampling converter branch "
                                 "(TRMSampleRateConverter.m:234-297) is not on the HIP path yet", d.sampleRate, (double)params->outputRate);
@@ -261,8 +263,8 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     {   // diagnostic library only: per-workgroup, per-role {work, wait} cycle sums; read back with
         // trm_batch_noise_table-like copy in tools/stage_profile.py via TRM_STAMP_PTR
         static unsigned long long *dStamps = nullptr;
-        if (!dStamps) HIP_TRY(hipMalloc((void **)&dStamps, 65536 * 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(dStamps, 0, 65536 * 8 * sizeof(unsigned long long), stream));
+        if (!dStamps) HIP_TRY(hipMalloc((void **)&dStamps, 65536 * 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(dStamps, 0, 65536 * 16 * sizeof(unsigned long long), stream));
         a.stamps = dStamps;
         g_stampPtr = dStamps;
     }

@@ -23,15 +23,16 @@
 namespace trm {
 
 constexpr int kWave = 64;
-constexpr int kRoles = 4;            // waves per workgroup: excite, coef, tube, convert
+constexpr int kRoles = 6;            // waves per workgroup: excite, coef x2, tube, convert x2
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
-constexpr int kTile = 16;            // outputs per staged half-tile; the staging ring holds two halves
-constexpr int kTileStride = 2 * kTile + 4;   // 16-byte aligned rows for b128 row reads
-constexpr int kRowSlots = 64;        // converter coefficient ring: one slot per output sample
-constexpr int kRowHalf = 32;         //   refilled by halves, one half ahead
-constexpr int kSlotFloats = 32;      //   slot = left-wing row (16 floats) + right-wing row (16 floats)
 constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
 constexpr int kNoiseHalf = 64;
+// tube -> convert hand-off: per voice a ring of the last 128 tube-rate samples, plus a mirror of its
+// first 26 slots so that a 26-sample window never wraps; odd row stride = conflict-free columns
+constexpr int kYRing = 128;
+constexpr int kYStride = kYRing + kSrcWindow + 1;
+constexpr int kCvtCols = 32;         // convert: outputs per block (lanes 0-31 / 32-63 = two voices)
+constexpr int kCvtRows = kWave / 2;  // convert: wave-rows per block (two voices each)
 
 __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *state)
 {
@@ -109,19 +110,24 @@ __device__ __forceinline__ void load_frame(const float *frames, uint32_t fi, flo
     }
 }
 
-// One workgroup = 64 voices (one per lane) x 4 waves (one per pipeline stage).  At step i the
-// excite and coef waves produce block i (kTB tube samples) into LDS, the tube wave consumes block
-// i-1 and produces tube-rate samples, the convert wave consumes block i-2 and writes PCM.  One
-// barrier per step; every hand-off buffer is double-buffered.
+// One workgroup = 64 voices x 6 waves.
+//   excite, coef x2, tube: lane = voice.  At step i the excite wave and the two coef waves (one per
+//     sample parity; the coefficient stage is stateless in time) produce block i (kTB tube samples)
+//     into LDS, the tube wave consumes block i-1 and appends its tube-rate samples to a per-voice ring
+//     in LDS.  Hand-off buffers are double-buffered; one barrier per step.
+//   convert x2: lane = OUTPUT TIME.  The converter is a feed-forward FIR, so it runs transposed: a
+//     wave-row is 32 consecutive output samples of two voices (lanes 0-31 / 32-63).  All 64 voices
+//     share the block's 32 phases, so each lane keeps its 26 coefficients in VGPRs for 32 rows; the
+//     26-sample windows come out of the ring as conflict-free LDS reads, and every row is stored
+//     straight from registers as two contiguous 128-byte pieces of PCM -- no transposition tile, no
+//     per-output control flow.  The two convert waves take alternate row pairs; a fixed number of
+//     rows per step keeps them ahead of production.
 __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // excitation per sample
     __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * 6 * kWave];      // coefficients per sample
-    __shared__ float sY[2 * kTB * kWave];                                        // tube-rate samples
-    __shared__ float sStage[kWave * kTileStride];                                // convert: output tile
-    __shared__ __attribute__((aligned(16))) float sRows[kRowSlots * kSlotFloats]; // convert: coefficient ring
-    __shared__ float *sOutPtr[kWave];                                            // convert: row destinations
-    __shared__ uint32_t sOutLen[kWave];                                          // convert: row lengths
+    __shared__ float sY[kWave * kYStride];                                       // tube-rate rings
+    __shared__ float sMax[kWave];                                                // convert: per-voice max |y|
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
     __shared__ float sFir[32];                                                   // excite: FIR taps
     __shared__ float sSine[kTableLen];                                           // excite: sine table
@@ -135,14 +141,26 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     const uint32_t nfr = A.nframes[v];
     const uint32_t nfrMax = wave_max_u32(nfr);          // same 64 voices in every wave of the group
     const uint32_t CP = (uint32_t)C.controlPeriod;
+    const uint32_t inc = C.timeRegisterIncrement;
     const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
     // (nfrMax-1) control periods, then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93).
     // Lanes whose utterance is shorter than the group's longest keep stepping on their last frame;
-    // the convert stage forces their converter input to 0 and masks their stores.
+    // the tube stage hands zeros to the converter past a voice's own end.
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
-    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 2 : 0;
+    // Output rows (64 lanes) a step's kTB tube samples turn into: kTB * 2^16/inc; the convert waves get
+    // strictly more than that per step, in row pairs, split between the two waves.
+    const uint32_t rowsPerStep = (kTB * 65536u) / inc + 1;
+    const uint32_t pairsPerWave = ((rowsPerStep + 1) / 2 + 1) / 2;
+    // the last tube block is written at step ceil(nTotal/kTB), readable one step later; the convert waves
+    // are never more than one block (16 pairs, 8 per wave) behind
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 2 + 2 * ((8 + pairsPerWave - 1) / pairsPerWave) + 2 : 0;
     // a voice without frames (a silent no-op, TRMTubeModel.m:274-277) reads row 0 of the buffer
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
+    const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
+
+    for (int i = threadIdx.x; i < kWave * kYStride; i += kWave * kRoles) sY[i] = 0.0f;   // 25 zeros of pre-roll
+    if (threadIdx.x < kWave) sMax[threadIdx.x] = 0.0f;
+    __syncthreads();
 
     if (role == 0) {
         // ------------------------------------------------------------ excite
@@ -198,46 +216,47 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         }
         STAMP_STORE(role)
         dma_wait_all();   // nothing may still be writing LDS when the wave ends
-    } else if (role == 1) {
-        // ------------------------------------------------------------ coef
+    } else if (role == 1 || role == 2) {
+        // ------------------------------------------------------------ coef (this wave: samples of parity u)
+        const int u = role - 1;
         CoefTrack T;
         float cur[16], prev[16];
         if (nSteps > 0) load_frame(frames, 0, cur, 4);
-        uint32_t j = CP, f = 0;
+        // position of this wave's next sample in its control period; the first sample starts period 1
+        uint32_t j = CP + (uint32_t)u, f = 0;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             const int buf = step & 1;
-            for (int u = 0; u < kTB; u++) {
-                const uint32_t n = step * kTB + u;
-                if (n < nTotal) {
-                    if (j == CP) {
-                        j = 0;
-                        f++;
-                        for (int q = 0; q < 16; q++) prev[q] = cur[q];
-                        load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 4);
-                        coef_track_setup(T, C, prev, cur);
-                    }
-                    Coefs K = coef_sample(T, C, (int)j);
-                    j++;
-                    float4 *dst = &sK[((buf * kTB + u) * 6) * kWave + lane];
-                    dst[0 * kWave] = make_float4(K.k[0], K.k[1], K.k[2], K.k[3]);
-                    dst[1 * kWave] = make_float4(K.k[4], K.k[5], K.k[6], K.k[7]);
-                    dst[2 * kWave] = make_float4(K.onePlusK8, K.alphaLR, K.alphaU, K.nk1);
-                    dst[3 * kWave] = make_float4(K.tap[0], K.tap[1], K.tap[2], K.tap[3]);
-                    dst[4 * kWave] = make_float4(K.tap[4], K.tap[5], K.tap[6], K.tap[7]);
-                    dst[5 * kWave] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
+            const uint32_t n = step * kTB + u;
+            if (n < nTotal) {
+                if (j >= CP) {      // the host guarantees CP >= 2*kTB: at most one period boundary per step
+                    j -= CP;
+                    f++;
+                    for (int q = 0; q < 16; q++) prev[q] = cur[q];
+                    load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 4);
+                    coef_track_setup(T, C, prev, cur);
                 }
+                Coefs K = coef_sample(T, C, (int)j);
+                j += kTB;
+                float4 *dst = &sK[((buf * kTB + u) * 6) * kWave + lane];
+                dst[0 * kWave] = make_float4(K.k[0], K.k[1], K.k[2], K.k[3]);
+                dst[1 * kWave] = make_float4(K.k[4], K.k[5], K.k[6], K.k[7]);
+                dst[2 * kWave] = make_float4(K.onePlusK8, K.alphaLR, K.alphaU, K.nk1);
+                dst[3 * kWave] = make_float4(K.tap[0], K.tap[1], K.tap[2], K.tap[3]);
+                dst[4 * kWave] = make_float4(K.tap[4], K.tap[5], K.tap[6], K.tap[7]);
+                dst[5 * kWave] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
             }
             STAMP_MID
             __syncthreads();
             STAMP_END
         }
         STAMP_STORE(role)
-    } else if (role == 2) {
+    } else if (role == 3) {
         // ------------------------------------------------------------ tube
         TubeState S;
         tube_reset(S);
+        float *const ring = &sY[lane * kYStride];
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
@@ -260,7 +279,12 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
                         K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
                         K.bpAlpha = bp.x; K.bpBeta = bp.y; K.bpGamma = bp.z; K.pad_ = 0.0f;
-                        sY[(buf * kTB + u) * kWave + lane] = tube_sample(S, C, E, K);
+                        float y = tube_sample(S, C, E, K);
+                        y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
+                        // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
+                        const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
+                        ring[slot] = y;
+                        if (slot < (uint32_t)kSrcWindow) ring[slot + kYRing] = y;   // mirror: windows never wrap
                     }
                 }
             }
@@ -270,154 +294,103 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         }
         STAMP_STORE(role)
     } else {
-        // ------------------------------------------------------------ convert
-        float *const outBase = A.out + A.out_offset[v];
-        const uint32_t inc = C.timeRegisterIncrement;
-        const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
+        // ------------------------------------------------------------ convert (lane = output time)
+        const uint32_t cw = (uint32_t)(role - 4);   // this wave takes row pairs cw, cw+2, ... of every block
         uint32_t noutLane = 0;
         if (nfr > 0) {
             uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
             noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
         }
         if (!laneValid) noutLane = 0;
-        sOutPtr[lane] = outBase;         // read back row-wise by the tile flush (this wave only)
-        sOutLen[lane] = noutLane;
-        SrcState<kTB> S;
-        src_reset(S);
-        // Converter coefficients for output k live in slot k & 63.  Output k's phase is (k*inc) mod 2^16
-        // (TRMSampleRateConverter.m:221-232), so rows can be fetched ahead by output index alone.
-        // One DMA instruction fills 8 slots: lane -> slot (lane>>3), 16-byte part (lane&7) = {L q0..3, R q0..3}.
-        auto fill_rows_half = [&](uint32_t kFirst, int half) {
-            for (int jj = 0; jj < 4; jj++) {
-                uint32_t k = kFirst + (uint32_t)(jj * 8 + (lane >> 3));
-                uint32_t ph = (k * inc) & 0xFFFFu;
-                uint32_t row = (lane & 4) ? 0xFFFFu - ph : ph;
-                dma16(A.src_rows + (size_t)row * kSrcRow + (lane & 3) * 4,
-                      &sRows[(half * kRowHalf + jj * 8) * kSlotFloats]);
-            }
+        // per-voice values stay in the VGPRs of lane == voice and are broadcast per row with v_readlane
+        const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v]);
+        const uint32_t myLo = (uint32_t)myOut, myHi = (uint32_t)(myOut >> 32);
+        const uint32_t noutMax = wave_max_u32(noutLane);
+        const uint32_t nBlocks = (noutMax + kCvtCols - 1) / kCvtCols;
+        const int col = lane & (kCvtCols - 1);      // output within the block
+        const bool upper = lane >= kCvtCols;        // which of a row's two voices
+        auto pick = [&](uint32_t x, int voiceEven) {   // x of voice voiceEven (lanes 0-31) / voiceEven+1 (lanes 32-63)
+            uint32_t a = __builtin_amdgcn_readlane(x, voiceEven);
+            uint32_t b = __builtin_amdgcn_readlane(x, voiceEven + 1);
+            return upper ? b : a;
         };
-        // Two coefficient register sets used alternately inside a step; set A always holds the rows of the
-        // step's first output, fetched at the end of the previous step so the LDS latency hides behind the
-        // barrier.  Inside the step the rows of output o+1 are requested before the 26 FMAs of output o.
-        float cA[32], cB[32];
-        auto load_rows = [&](float *c, uint32_t k) {
-            const float4 *rp = reinterpret_cast<const float4 *>(&sRows[(k & (kRowSlots - 1)) * kSlotFloats]);
-            for (int q = 0; q < 8; q++) {
-                float4 a = rp[q];
+
+        // the 26 coefficients of this lane's output phase, in window order (trm_setup.cc build_src_rows)
+        float cc[28], nc[28];
+        auto fetch_row = [&](uint32_t blk, float *c) {
+            const uint32_t ph = src_phase(blk * kCvtCols + col, inc);
+            const float4 *pc = reinterpret_cast<const float4 *>(A.src_rows + (size_t)ph * kSrcRowC);
+            for (int q = 0; q < 7; q++) {
+                float4 a = pc[q];
                 c[4 * q] = a.x; c[4 * q + 1] = a.y; c[4 * q + 2] = a.z; c[4 * q + 3] = a.w;
             }
         };
-        if (nSteps > 0) {
-            fill_rows_half(0, 0);
-            fill_rows_half(kRowHalf, 1);
-            dma_wait_all();
-            load_rows(cA, 0);
+        uint32_t blk = 0, row = 2 * cw; // next work item: wave-rows `row`, `row`+1 (voices 2*row .. 2*row+3) of block `blk`
+        uint32_t winBase = 0;           // this lane's window start inside a voice's ring (floats)
+        uint32_t kLane = 0;             // this lane's output index
+        uint32_t needLast = 0;          // last tube sample the current block reads (uniform)
+        auto begin_block = [&]() {
+            kLane = blk * kCvtCols + col;
+            winBase = src_position(kLane, inc) & (kYRing - 1);
+            // highest tube sample the block reads: the window of output k ends at tube sample e_k; outputs past
+            // the longest voice's end are masked, so the last block only waits for the final sample
+            needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
+            needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
+            for (int q = 0; q < 28; q++) cc[q] = nc[q];
+            if (blk + 1 < nBlocks) fetch_row(blk + 1, nc);          // prefetch the next block's coefficients
+        };
+        if (nBlocks > 0) {
+            fetch_row(0, nc);
+            begin_block();
         }
-        uint32_t e = 0;           // converter read position, in pushed samples (uniform)
-        uint32_t t = 0;           // 16.16 time register, N part cleared (uniform)
-        uint32_t kout = 0;        // outputs emitted (uniform)
-        uint32_t kflushed = 0;    // outputs written to HBM (uniform, multiple of kTile)
-        uint32_t rowsHalfDone = 0;   // ring halves already re-requested (uniform)
-
-        // outputs belonging to tube sample n: those k with floor(k*inc / 2^16) == n (uniform, scalar only)
-        auto count_outputs = [&](uint32_t n) {
-            uint32_t c = 0;
-            while (e <= n) {
-                t += inc;
-                e += t >> 16;
-                t &= 0xFFFFu;
-                c++;
-            }
-            return c;
-        };
-        auto emit_one = [&](const float *cur, float *nxt, bool second) {
-#if TRM_ABL != 2
-            load_rows(nxt, kout + 1);
-#endif
-#if TRM_ABL == 3
-            float y = cur[0] + cur[16] + S.src[second ? 1 : 0];
-#else
-            float y = second ? src_emit_up<kTB, 1>(S, cur, cur + 16) : src_emit_up<kTB, 0>(S, cur, cur + 16);
-#endif
-            float a = fabsf(y);
-            S.maxAbs = (kout < noutLane && a > S.maxAbs) ? a : S.maxAbs;
-            sStage[lane * kTileStride + (kout & (2 * kTile - 1))] = y;
-            kout++;
-        };
-        // one half (kTile outputs) of the staging ring -> HBM: 16 rows per pass, lane -> row (lane>>2),
-        // 16-byte piece (lane&3); a row is 64 contiguous bytes
-        auto flush_half = [&]() {
-#if TRM_ABL == 1
-            kflushed += kTile;
-            return;
-#endif
-            const uint32_t c4 = (uint32_t)(lane & 3) * 4u;
-            const uint32_t col = (kflushed & (2 * kTile - 1)) + c4;
-            const uint32_t k = kflushed + c4;
-#pragma unroll
-            for (int it = 0; it < kWave / 16; it++) {
-                const int row = it * 16 + (lane >> 2);
-                float *dst = sOutPtr[row] + k;
-                const uint32_t lim = sOutLen[row];
-                const float4 val = *reinterpret_cast<const float4 *>(&sStage[row * kTileStride + col]);
-                if (k + 3 < lim && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-                    *reinterpret_cast<float4 *>(dst) = val;
-                } else {
-                    if (k < lim) dst[0] = val.x;
-                    if (k + 1 < lim) dst[1] = val.y;
-                    if (k + 2 < lim) dst[2] = val.z;
-                    if (k + 3 < lim) dst[3] = val.w;
-                }
-            }
-            kflushed += kTile;
-        };
-
+        typedef __attribute__((address_space(1))) float *GlobalFloatPtr;
+        typedef __attribute__((address_space(3))) float *LdsFloatPtr;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 2) {
-                const uint32_t blk = step - 2;
-                const int buf = blk & 1;
-                float sv[kTB];
-                for (int u = 0; u < kTB; u++) {
-                    const uint32_t n = blk * kTB + u;
-                    float s = sY[(buf * kTB + u) * kWave + lane];
-                    sv[u] = (n < ntubeLane && n < nTotal) ? s : 0.0f;
+            // visible after the previous barrier: tube samples n < (step-1)*kTB
+            const uint32_t ready = step >= 1 ? (step - 1) * kTB : 0;
+            for (uint32_t it = 0; it < pairsPerWave; it++) {
+                if (blk < nBlocks && needLast < ready) {
+                    // two wave-rows at a time = four voices: their LDS reads and FMA chains overlap
+                    const int va = (int)row * 2, vb = va + 2;
+                    const int sa = va + (upper ? 1 : 0), sb = vb + (upper ? 1 : 0);
+                    const float *wa = &sY[sa * kYStride + winBase];
+                    const float *wb = &sY[sb * kYStride + winBase];
+                    float winA[kSrcWindow], winB[kSrcWindow];
+                    for (int q = 0; q < kSrcWindow; q++) { winA[q] = wa[q]; winB[q] = wb[q]; }
+                    const uint32_t lenA = pick(noutLane, va), lenB = pick(noutLane, vb);
+                    const uint32_t loA = pick(myLo, va), hiA = pick(myHi, va);
+                    const uint32_t loB = pick(myLo, vb), hiB = pick(myHi, vb);
+                    const float ya = src_dot(winA, cc);
+                    const float yb = src_dot(winB, cc);
+                    const bool okA = kLane < lenA, okB = kLane < lenB;
+                    if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiA << 32) | loA)[kLane] = ya;
+                    if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiB << 32) | loB)[kLane] = yb;
+                    // running per-voice max |y| (TRMSampleRateConverter.m:206-208): LDS float-max atomics
+                    __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMax[sa], okA ? fabsf(ya) : 0.0f, 0, 0, false);
+                    __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMax[sb], okB ? fabsf(yb) : 0.0f, 0, 0, false);
+                    row += 4;
+                    if (row >= (uint32_t)kCvtRows) {
+                        row = 2 * cw;
+                        blk++;
+                        if (blk < nBlocks) begin_block();
+                    }
                 }
-                src_push_block<kTB>(S, sv);
-                // about to read coefficient slots of the next ring half: its DMA (issued most of a half
-                // ago) must have landed
-                if (((kout + 8) / kRowHalf) > rowsHalfDone) dma_wait_all();
-                const uint32_t n0 = blk * kTB;
-                const uint32_t cnt0 = n0 < nTotal ? count_outputs(n0) : 0;
-                const uint32_t cntAll = cnt0 + (n0 + 1 < nTotal ? count_outputs(n0 + 1) : 0);
-                // straight-line emission, register sets alternate A, B, A, ... from the step's first output
-                for (uint32_t o = 0; o < cntAll; o += 2) {
-                    emit_one(cA, cB, o >= cnt0);
-                    if (o + 1 < cntAll) emit_one(cB, cA, o + 1 >= cnt0);
-                    else load_rows(cA, kout);      // odd count: the next step starts from set A again
-                }
-                // single-site housekeeping: coefficient ring refill, staged tile flush
-                if ((kout / kRowHalf) > rowsHalfDone) {
-                    // a ring half has been fully consumed: wait for the DMA issued one half ago, refill it
-                    dma_wait_all();
-                    rowsHalfDone++;
-                    fill_rows_half((rowsHalfDone + 1) * kRowHalf, (rowsHalfDone + 1) & 1);
-                }
-                if (kout - kflushed >= kTile) flush_half();
             }
             STAMP_MID
             __syncthreads();
             STAMP_END
         }
         STAMP_STORE(role)
-        while (kflushed < kout) flush_half();     // tail (rows are masked by their own lengths)
-        dma_wait_all();
-        if (laneValid) {
+        __syncthreads();   // both convert waves have deposited their maxima (matched by the other roles below)
+        if (cw == 0 && laneValid) {
             A.number_samples[vRaw] = noutLane;
-            A.max_sample[vRaw] = S.maxAbs;
+            A.max_sample[vRaw] = sMax[lane];
         }
+        return;
     }
+    __syncthreads();       // pairs with the convert waves' final barrier
 }
 
 // Output normalisation (TRMTubeModel.m:370-389 file path, :515-533 WAV-data path).  One

@@ -43,7 +43,6 @@ constexpr int kFirUnique = 25;      // 49 symmetric taps (TRMFIRFilter.h:7-9 des
 constexpr int kFirTaps = 49;
 constexpr int kSrcWing = 13;        // ZERO_CROSSINGS (TRMSampleRateConverter.m:10)
 constexpr int kSrcWindow = 26;
-constexpr int kSrcRow = 16;         // coefficient row, 13 used + 3 pad
 constexpr int kTableLen = 512;      // TRMWavetable.m:22
 constexpr float kVtScale = 0.125f;  // TRMTubeModel.m:72
 
@@ -252,7 +251,7 @@ TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, 
 
 // ================================================================ stage 2: coefficients
 struct CoefTrack {
-    double fricPos, fricPosDelta;
+    double fricPos0, fricPosDelta;
     // fp32 base + delta: fricVol, fricCF, fricBW, r1..r8, velum
     float base[12], delta[12];
 };
@@ -271,8 +270,8 @@ constexpr int kCoefFloats = 24;
 // frame columns: 3 fricVol, 4 fricPos, 5 fricCF, 6 fricBW, 7..14 radii, 15 velum
 TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, const float *cur)
 {
-    T.fricPos = (double)prev[4];
-    T.fricPosDelta = ((double)cur[4] - T.fricPos) / (double)C.controlPeriod;
+    T.fricPos0 = (double)prev[4];
+    T.fricPosDelta = ((double)cur[4] - T.fricPos0) / (double)C.controlPeriod;
     const int col[12] = {3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
     for (int i = 0; i < 12; i++) {
         T.base[i] = prev[col[i]];
@@ -280,7 +279,8 @@ TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, co
     }
 }
 
-TRM_HD Coefs coef_sample(CoefTrack &T, const Const &C, int j)
+// Stateless in the sample index: any wave may compute any sample j of the current control period.
+TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
 {
     Coefs K;
     const float fj = (float)j;
@@ -308,8 +308,9 @@ TRM_HD Coefs coef_sample(CoefTrack &T, const Const &C, int j)
 
     // frication taps (:748-773)
     float fricAmp = amplitude_f(fricDb);
-    int ip = (int)T.fricPos;
-    float comp = (float)(T.fricPos - (double)ip);
+    const double fricPos = T.fricPos0 + (double)j * T.fricPosDelta;   // (:676-688), fp64: feeds (int)
+    int ip = (int)fricPos;
+    float comp = (float)(fricPos - (double)ip);
     float tapA = (1.0f - comp) * fricAmp;       // tap[ip]
     float tapB = comp * fricAmp;                // tap[ip+1] when ip+1 < 8
     K.tap[0] = ip == 0 ? tapA : 0.0f;
@@ -341,7 +342,6 @@ TRM_HD Coefs coef_sample(CoefTrack &T, const Const &C, int j)
         K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
     }
     K.pad_ = 0.0f;
-    T.fricPos += T.fricPosDelta;                // (:351)
     return K;
 }
 
@@ -444,47 +444,26 @@ TRM_HD float tube_sample(TubeState &L, const Const &C, const Excitation &E, cons
 }
 
 // ================================================================ stage 4: sample-rate conversion
-// The converter keeps the last 26 tube-rate samples per lane (TRMRingBuffer.m:47-60 as a sliding
-// window).  The window array holds kSrcWindow + B - 1 samples so that a block of B pushes costs one
-// shift by B; sample u of the block sees src[u .. u+25].
-template <int B>
-struct SrcState {
-    float src[kSrcWindow + B - 1];
-    float maxAbs;
-};
+// One up-sampled output (TRMSampleRateConverter.m:171-233): 13 left + 13 right taps over the 26
+// tube-rate samples w[0..25] = s[e-25 .. e], e = the converter's read position for this output.
+// c[0..25] is the phase's combined coefficient row: c[i] = left-wing coefficient 12-i for i < 13,
+// right-wing coefficient i-13 for i >= 13, so the output is one straight dot product.  Even and odd
+// terms accumulate separately (two-wide packed FMAs on the device).
+constexpr int kSrcRowC = 32;        // combined row: 26 coefficients + 6 pad = 128 bytes per phase
 
-template <int B>
-TRM_HD void src_reset(SrcState<B> &L)
+TRM_HD float src_dot(const float *w, const float *c)
 {
-    for (int i = 0; i < kSrcWindow + B - 1; i++) L.src[i] = 0.f;
-    L.maxAbs = 0.f;
-}
-
-// Shift the window by B and append the block's B new samples.
-template <int B>
-TRM_HD void src_push_block(SrcState<B> &L, const float *s)
-{
-    for (int i = 0; i < kSrcWindow - 1; i++) L.src[i] = L.src[i + B];
-    for (int u = 0; u < B; u++) L.src[kSrcWindow - 1 + u] = s[u];
-}
-
-// One up-sampled output (TRMSampleRateConverter.m:171-233): 13 left + 13 right taps around the
-// window of block sample U.  cl/cr = coefficient rows for the left wing (phase f) and right wing
-// (phase ~f).  Four independent partial sums keep the FMA pipeline busy.
-template <int B, int U>
-TRM_HD float src_emit_up(const SrcState<B> &L, const float *cl, const float *cr)
-{
-    const float *w = L.src + U;
-    float a0 = w[12] * cl[0], a1 = w[11] * cl[1], a2 = w[13] * cr[0], a3 = w[14] * cr[1];
-    for (int i = 2; i < kSrcWing - 1; i += 2) {
-        a0 = fma_f(w[12 - i], cl[i], a0);
-        a1 = fma_f(w[11 - i], cl[i + 1], a1);
-        a2 = fma_f(w[13 + i], cr[i], a2);
-        a3 = fma_f(w[14 + i], cr[i + 1], a3);
+    float a0 = w[0] * c[0], a1 = w[1] * c[1];
+    for (int i = 2; i < kSrcWindow; i += 2) {
+        a0 = fma_f(w[i], c[i], a0);
+        a1 = fma_f(w[i + 1], c[i + 1], a1);
     }
-    a0 = fma_f(w[0], cl[12], a0);
-    a2 = fma_f(w[25], cr[12], a2);
-    return (a0 + a1) + (a2 + a3);
+    return a0 + a1;
 }
+
+// Converter bookkeeping in closed form (TRMSampleRateConverter.m:221-232): output k sits at input
+// time k*inc (16.16 fixed point): phase = low 16 bits, read position e = high part.
+TRM_HD uint32_t src_phase(uint32_t k, uint32_t inc) { return (k * inc) & 0xFFFFu; }
+TRM_HD uint32_t src_position(uint32_t k, uint32_t inc) { return (uint32_t)(((uint64_t)k * inc) >> 16); }
 
 }  // namespace trm

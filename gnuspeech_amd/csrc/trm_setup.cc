@@ -137,13 +137,18 @@ void build_src_rows(std::vector<float> &rows)
 {
     std::vector<double> h, dh;
     build_src_h(h, dh);
-    rows.assign((size_t)65536 * kSrcRow, 0.0f);
+    rows.assign((size_t)65536 * kSrcRowC, 0.0f);
+    // coefficient of tap i of a wing at 16-bit phase g (TRMSampleRateConverter.m:182-190)
+    auto wing = [&](uint32_t g, int i) {
+        uint32_t l = g >> 8, m = g & 255;
+        uint32_t fi = l + 256u * (uint32_t)i;
+        return (float)(h[fi] + dh[fi] * ((double)m / 256.0));
+    };
     for (uint32_t f = 0; f < 65536; f++) {
-        uint32_t l = f >> 8, m = f & 255;
-        double interp = (double)m / 256.0;
+        float *c = &rows[(size_t)f * kSrcRowC];
         for (int i = 0; i < kSrcWing; i++) {
-            uint32_t fi = l + 256u * i;
-            rows[(size_t)f * kSrcRow + i] = (float)(h[fi] + dh[fi] * interp);
+            c[12 - i] = wing(f, i);                 // left wing, phase f, walks back from s[e-13]
+            c[13 + i] = wing(0xFFFFu - f, i);       // right wing, phase ~f (:193-203), walks on from s[e-12]
         }
     }
 }

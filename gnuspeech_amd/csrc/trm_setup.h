@@ -22,8 +22,9 @@ int design_fir(double beta, double gamma, double cutoff, std::vector<double> &ta
 // h[] / deltaH[] of the converter (TRMSampleRateConverter.m:110-131), 3328 doubles each.
 void build_src_h(std::vector<double> &h, std::vector<double> &dh);
 
-// Up-sampling coefficient rows: row[f][i] = h[l+256i] + deltaH[l+256i]*m/256 for the 16-bit
-// phase f = (l<<8)|m, i < 13 (TRMSampleRateConverter.m:182-203); 65536 x kSrcRow floats.
+// Up-sampling coefficient rows, one 128-byte row per 16-bit phase f = (l<<8)|m: 26 coefficients in
+// window order (left wing h[l+256i] + deltaH[l+256i]*m/256 reversed, then the right wing at phase ~f;
+// TRMSampleRateConverter.m:182-203); 65536 x kSrcRowC floats.
 void build_src_rows(std::vector<float> &rows);
 
 // Fine table for the down-sampling branch: fine[q] = h[q>>8] + deltaH[q>>8]*(q&255)/256,

@@ -36,25 +36,12 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
             x1 = nz;
         }
     }
-    ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS; SrcState<1> SS;
-    excite_reset(ES); tube_reset(TS); src_reset(SS);
-    uint32_t t = 0; uint64_t e = 0, n = 0, k = 0;
+    ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS;
+    excite_reset(ES); tube_reset(TS);
     auto sineLookup = [&](int i) { return sine[i]; };
-    auto push = [&](float s) {
-        src_push_block<1>(SS, &s);
-        while (e <= n) {
-            uint32_t f = t & 0xFFFF;
-            float y = src_emit_up<1, 0>(SS, &rows[(size_t)f * kSrcRow], &rows[(size_t)(0xFFFF - f) * kSrcRow]);
-            if (k < cap) out[k] = y;
-            k++;
-            float a = fabsf(y);
-            if (a > SS.maxAbs) SS.maxAbs = a;
-            t += C.timeRegisterIncrement;
-            e += t >> 16;
-            t &= 0xFFFF;
-        }
-        n++;
-    };
+    // tube-rate signal, with the converter's 25 zeros of pre-roll and 2*pad zeros of flush around it
+    std::vector<float> sig(25 + ntube + 2 * C.padSize, 0.0f);
+    size_t n = 0;
     for (size_t f = 1; f < nframes; f++) {
         excite_track_setup(ET, C, frames + 16 * (f - 1), frames + 16 * f);
         coef_track_setup(CT, C, frames + 16 * (f - 1), frames + 16 * f);
@@ -63,11 +50,21 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
             Coefs K = coef_sample(CT, C, j);
             float s = tube_sample(TS, C, E, K);
             if (tube) tube[n] = s;
-            push(s);
+            sig[25 + n] = s;
+            n++;
         }
     }
-    for (int i = 0; i < 2 * C.padSize; i++) push(0.0f);
-    *nout = (uint32_t)k;
-    *maxv = SS.maxAbs;
+    uint64_t total = count_outputs(d, ntube);
+    float mx = 0.f;
+    for (uint64_t k = 0; k < total; k++) {
+        uint32_t ph = src_phase((uint32_t)k, C.timeRegisterIncrement);
+        uint32_t e = src_position((uint32_t)k, C.timeRegisterIncrement);
+        float y = src_dot(&sig[e], &rows[(size_t)ph * kSrcRowC]);
+        if (k < cap) out[k] = y;
+        float a = fabsf(y);
+        if (a > mx) mx = a;
+    }
+    *nout = (uint32_t)total;
+    *maxv = mx;
     return TRM_OK;
 }
