@@ -69,7 +69,7 @@ struct trm_batch {
     int device = 0;
     hipStream_t stream = nullptr;        // used by the host-buffer entry points
     trm::Const *dConst = nullptr;
-    float *dRows = nullptr, *dSine = nullptr;
+    float *dRowsAlloc = nullptr, *dRows = nullptr, *dSine = nullptr;
     DevBuf<float> dNoise;
     double *dNoiseState = nullptr;
     uint32_t noiseLen = 0;
@@ -169,7 +169,10 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipStreamCreate(&b->stream));
     B_TRY(hipMalloc((void **)&b->dConst, sizeof(trm::Const)));
     B_TRY(hipMemcpy(b->dConst, &b->c, sizeof(trm::Const), hipMemcpyHostToDevice));
-    B_TRY(hipMalloc((void **)&b->dRows, rows.size() * sizeof(float)));
+    // 4 zero floats in front of row 0: the convert stage fetches rows shifted by up to 3 floats
+    B_TRY(hipMalloc((void **)&b->dRowsAlloc, (rows.size() + 4) * sizeof(float)));
+    B_TRY(hipMemset(b->dRowsAlloc, 0, 4 * sizeof(float)));
+    b->dRows = b->dRowsAlloc + 4;
     B_TRY(hipMemcpy(b->dRows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dSine, sine.size() * sizeof(float)));
     B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -185,7 +188,7 @@ void trm_batch_destroy(trm_batch *b)
     (void)hipSetDevice(b->device);
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (b->dConst) (void)hipFree(b->dConst);
-    if (b->dRows) (void)hipFree(b->dRows);
+    if (b->dRowsAlloc) (void)hipFree(b->dRowsAlloc);
     if (b->dSine) (void)hipFree(b->dSine);
     if (b->dNoiseState) (void)hipFree(b->dNoiseState);
     if (b->stream) (void)hipStreamDestroy(b->stream);

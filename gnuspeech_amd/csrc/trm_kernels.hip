@@ -27,12 +27,11 @@ constexpr int kRoles = 6;            // waves per workgroup: excite, coef x2, tu
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
 constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
 constexpr int kNoiseHalf = 64;
-// tube -> convert hand-off: per voice a ring of the last 128 tube-rate samples, plus a mirror of its
-// first 26 slots so that a 26-sample window never wraps; odd row stride = conflict-free columns
+// tube -> convert hand-off: per voice a ring of the last 128 tube-rate samples (+ mirror)
 constexpr int kYRing = 128;
-constexpr int kYStride = kYRing + kSrcWindow + 1;
+constexpr int kYMirror = 32;          // slots 0..31 repeated after the ring: a 32-sample aligned window never wraps
+constexpr int kYStride = kYRing + kYMirror + 4;   // multiple of 4 floats: 16-byte aligned rows for ds_read_b128
 constexpr int kCvtCols = 32;         // convert: outputs per block (lanes 0-31 / 32-63 = two voices)
-constexpr int kCvtRows = kWave / 2;  // convert: wave-rows per block (two voices each)
 
 __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *state)
 {
@@ -85,16 +84,24 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // waiting at the step barrier.  In the product build these macros expand to nothing.
 #ifdef TRM_STAMP
 #define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0;
+#define SUB_DECL unsigned long long sub_t = 0, sub_acc[6] = {0, 0, 0, 0, 0, 0};
+#define SUB_START sub_t = __builtin_readcyclecounter();
+#define SUB_LAP(i_) { unsigned long long n_ = __builtin_readcyclecounter(); sub_acc[i_] += n_ - sub_t; sub_t = n_; }
+#define SUB_STORE(role_) if (lane == 0 && A.stamps) for (int i_ = 0; i_ < 6; i_++) A.stamps[(blockIdx.x * kRoles + (role_)) * 8 + 2 + i_] = sub_acc[i_];
 #define STAMP_BEGIN st_t0 = __builtin_readcyclecounter();
 #define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0;
 #define STAMP_END st_wait += __builtin_readcyclecounter() - st_t1;
 #define STAMP_STORE(role_)                                                          \
     if (lane == 0 && A.stamps) {                                                    \
-        A.stamps[(blockIdx.x * kRoles + (role_)) * 2] = st_work;                    \
-        A.stamps[(blockIdx.x * kRoles + (role_)) * 2 + 1] = st_wait;                \
+        A.stamps[(blockIdx.x * kRoles + (role_)) * 8] = st_work;                    \
+        A.stamps[(blockIdx.x * kRoles + (role_)) * 8 + 1] = st_wait;                \
     }
 #else
 #define STAMP_DECL
+#define SUB_DECL
+#define SUB_START
+#define SUB_LAP(i_)
+#define SUB_STORE(role_)
 #define STAMP_BEGIN
 #define STAMP_MID
 #define STAMP_END
@@ -126,14 +133,22 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
 {
     __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // excitation per sample
     __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * 6 * kWave];      // coefficients per sample
-    __shared__ float sY[kWave * kYStride];                                       // tube-rate rings
-    __shared__ float sMax[kWave];                                                // convert: per-voice max |y|
+    __shared__ __attribute__((aligned(16))) float sY[kWave * kYStride];          // tube-rate rings
+    __shared__ float sMx[2 * 16 * kWave];                                        // convert: running max |y| per (row, lane)
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
     __shared__ float sFir[32];                                                   // excite: FIR taps
     __shared__ float sSine[kTableLen];                                           // excite: sine table
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // wave -> role.  A workgroup's waves are dealt to the CU's 4 SIMDs in turn, so waves w and w+4 share
+    // one SIMD's issue slots: TRM_ROLE_PERM lists the role of each wave (diagnostic builds may override it).
+#ifndef TRM_ROLE_PERM
+#define TRM_ROLE_PERM 0, 1, 2, 3, 4, 5
+#endif
+    const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rolePerm[kRoles] = {TRM_ROLE_PERM};
+    int role = 0;
+    for (int i = 0; i < kRoles; i++) role = waveIdx == i ? rolePerm[i] : role;
     const uint32_t vRaw = blockIdx.x * kWave + lane;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
@@ -150,16 +165,16 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     // Output rows (64 lanes) a step's kTB tube samples turn into: kTB * 2^16/inc; the convert waves get
     // strictly more than that per step, in row pairs, split between the two waves.
     const uint32_t rowsPerStep = (kTB * 65536u) / inc + 1;
-    const uint32_t pairsPerWave = ((rowsPerStep + 1) / 2 + 1) / 2;
     // the last tube block is written at step ceil(nTotal/kTB), readable one step later; the convert waves
     // are never more than one block (16 pairs, 8 per wave) behind
-    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 2 + 2 * ((8 + pairsPerWave - 1) / pairsPerWave) + 2 : 0;
+    // (8 row pairs per wave per block, metered at just over the production rate: a block takes about as
+    // long as the 32*inc/2^16 tube samples it spans)
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 2 + 2 * ((kCvtCols * inc / 65536u) / kTB + 2) + 4 : 0;
     // a voice without frames (a silent no-op, TRMTubeModel.m:274-277) reads row 0 of the buffer
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
 
     for (int i = threadIdx.x; i < kWave * kYStride; i += kWave * kRoles) sY[i] = 0.0f;   // 25 zeros of pre-roll
-    if (threadIdx.x < kWave) sMax[threadIdx.x] = 0.0f;
     __syncthreads();
 
     if (role == 0) {
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
                         const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
                         ring[slot] = y;
-                        if (slot < (uint32_t)kSrcWindow) ring[slot + kYRing] = y;   // mirror: windows never wrap
+                        if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;   // mirror: windows never wrap
                     }
                 }
             }
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         STAMP_STORE(role)
     } else {
         // ------------------------------------------------------------ convert (lane = output time)
-        const uint32_t cw = (uint32_t)(role - 4);   // this wave takes row pairs cw, cw+2, ... of every block
+        const int cw = role - 4;                    // this wave converts voices 32*cw .. 32*cw+31
         uint32_t noutLane = 0;
         if (nfr > 0) {
             uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
@@ -314,29 +329,34 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             uint32_t b = __builtin_amdgcn_readlane(x, voiceEven + 1);
             return upper ? b : a;
         };
+        // running max |y| (TRMSampleRateConverter.m:206-208) per (row of this wave, lane) in LDS: row r covers
+        // voice 32*cw + 2*r (+1 in the upper half); folded across the 32 columns once, at the end
+        float *const mxTile = &sMx[cw * 16 * kWave];
+        for (int r = 0; r < 16; r++) mxTile[r * kWave + lane] = 0.0f;
 
-        // the 26 coefficients of this lane's output phase, in window order (trm_setup.cc build_src_rows)
-        float cc[28], nc[28];
+        // This lane's output reads a 16-byte ALIGNED 32-sample window (a lone wave issues wide LDS reads at
+        // full rate, narrow ones at a fraction of it): the window starts winOff = e & 3 samples early and
+        // the lane's 26 coefficients are fetched shifted right by winOff.  Coefficient rows are 32 floats
+        // (26 + 6 zeros) with 4 zeros in front of row 0, so the shifted fetch only ever picks up zeros.
+        float cc[32], nc[32];
         auto fetch_row = [&](uint32_t blk, float *c) {
-            const uint32_t ph = src_phase(blk * kCvtCols + col, inc);
-            const float4 *pc = reinterpret_cast<const float4 *>(A.src_rows + (size_t)ph * kSrcRowC);
-            for (int q = 0; q < 7; q++) {
-                float4 a = pc[q];
-                c[4 * q] = a.x; c[4 * q + 1] = a.y; c[4 * q + 2] = a.z; c[4 * q + 3] = a.w;
-            }
+            const uint32_t k = blk * kCvtCols + col;
+            const uint32_t off = src_position(k, inc) & 3u;
+            const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
+            for (int q = 0; q < 32; q++) c[q] = pc[q];
         };
-        uint32_t blk = 0, row = 2 * cw; // next work item: wave-rows `row`, `row`+1 (voices 2*row .. 2*row+3) of block `blk`
-        uint32_t winBase = 0;           // this lane's window start inside a voice's ring (floats)
+        uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..7) of block `blk`: voices 32*cw + 4*pr .. +3
+        uint32_t winBase = 0;           // this lane's aligned window start inside a voice's ring (floats)
         uint32_t kLane = 0;             // this lane's output index
         uint32_t needLast = 0;          // last tube sample the current block reads (uniform)
         auto begin_block = [&]() {
             kLane = blk * kCvtCols + col;
-            winBase = src_position(kLane, inc) & (kYRing - 1);
+            winBase = src_position(kLane, inc) & (kYRing - 1) & ~3u;
             // highest tube sample the block reads: the window of output k ends at tube sample e_k; outputs past
             // the longest voice's end are masked, so the last block only waits for the final sample
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            for (int q = 0; q < 28; q++) cc[q] = nc[q];
+            for (int q = 0; q < 32; q++) cc[q] = nc[q];
             if (blk + 1 < nBlocks) fetch_row(blk + 1, nc);          // prefetch the next block's coefficients
         };
         if (nBlocks > 0) {
@@ -345,52 +365,86 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         }
         typedef __attribute__((address_space(1))) float *GlobalFloatPtr;
         typedef __attribute__((address_space(3))) float *LdsFloatPtr;
+        // Work is metered so that it spreads evenly over the steps: each step earns `earn` (16.16) row pairs,
+        // a little more than the kTB tube samples of a step turn into (pairs of this wave per step =
+        // kTB * 2^16/inc / 4), and a pair runs when a whole one has been earned and its block is readable.
+        const uint32_t earn = (uint32_t)(((uint64_t)kTB << 32) / inc / 4) + 2048;
+        uint32_t credit = 0;
+        SUB_DECL
+        auto do_pair = [&]() {
+            SUB_START
+            // two wave-rows at a time = four voices: their LDS reads and FMA chains overlap
+            const int la = 4 * (int)pr, lb = la + 2;           // voices local to this wave
+            const int va = 32 * cw + la, vb = 32 * cw + lb;
+            const int ha = upper ? 1 : 0;
+            const float4 *wa = reinterpret_cast<const float4 *>(&sY[(va + ha) * kYStride + winBase]);
+            const float4 *wb = reinterpret_cast<const float4 *>(&sY[(vb + ha) * kYStride + winBase]);
+            float winA[32], winB[32];
+            for (int q = 0; q < 8; q++) {
+                float4 a = wa[q], b = wb[q];
+                winA[4 * q] = a.x; winA[4 * q + 1] = a.y; winA[4 * q + 2] = a.z; winA[4 * q + 3] = a.w;
+                winB[4 * q] = b.x; winB[4 * q + 1] = b.y; winB[4 * q + 2] = b.z; winB[4 * q + 3] = b.w;
+            }
+            SUB_LAP(0)
+            const uint32_t lenA = pick(noutLane, va), lenB = pick(noutLane, vb);
+            const uint32_t loA = pick(myLo, va), hiA = pick(myHi, va);
+            const uint32_t loB = pick(myLo, vb), hiB = pick(myHi, vb);
+            SUB_LAP(1)
+            const float ya = src_dot32(winA, cc);
+            const float yb = src_dot32(winB, cc);
+            SUB_LAP(2)
+            const bool okA = kLane < lenA, okB = kLane < lenB;
+            if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiA << 32) | loA)[kLane] = ya;
+            if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiB << 32) | loB)[kLane] = yb;
+            SUB_LAP(3)
+            // running max |y| per (row, lane): conflict-free LDS float-max, folded across columns at the end
+            __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&mxTile[(2 * pr) * kWave + lane], okA ? fabsf(ya) : 0.0f, 0, 0, false);
+            __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&mxTile[(2 * pr + 1) * kWave + lane], okB ? fabsf(yb) : 0.0f, 0, 0, false);
+            if (++pr == 8) {
+                pr = 0;
+                blk++;
+                if (blk < nBlocks) begin_block();
+            }
+            SUB_LAP(4)
+        };
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             // visible after the previous barrier: tube samples n < (step-1)*kTB
             const uint32_t ready = step >= 1 ? (step - 1) * kTB : 0;
-            for (uint32_t it = 0; it < pairsPerWave; it++) {
-                if (blk < nBlocks && needLast < ready) {
-                    // two wave-rows at a time = four voices: their LDS reads and FMA chains overlap
-                    const int va = (int)row * 2, vb = va + 2;
-                    const int sa = va + (upper ? 1 : 0), sb = vb + (upper ? 1 : 0);
-                    const float *wa = &sY[sa * kYStride + winBase];
-                    const float *wb = &sY[sb * kYStride + winBase];
-                    float winA[kSrcWindow], winB[kSrcWindow];
-                    for (int q = 0; q < kSrcWindow; q++) { winA[q] = wa[q]; winB[q] = wb[q]; }
-                    const uint32_t lenA = pick(noutLane, va), lenB = pick(noutLane, vb);
-                    const uint32_t loA = pick(myLo, va), hiA = pick(myHi, va);
-                    const uint32_t loB = pick(myLo, vb), hiB = pick(myHi, vb);
-                    const float ya = src_dot(winA, cc);
-                    const float yb = src_dot(winB, cc);
-                    const bool okA = kLane < lenA, okB = kLane < lenB;
-                    if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiA << 32) | loA)[kLane] = ya;
-                    if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiB << 32) | loB)[kLane] = yb;
-                    // running per-voice max |y| (TRMSampleRateConverter.m:206-208): LDS float-max atomics
-                    __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMax[sa], okA ? fabsf(ya) : 0.0f, 0, 0, false);
-                    __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMax[sb], okB ? fabsf(yb) : 0.0f, 0, 0, false);
-                    row += 4;
-                    if (row >= (uint32_t)kCvtRows) {
-                        row = 2 * cw;
-                        blk++;
-                        if (blk < nBlocks) begin_block();
-                    }
-                }
+            credit += earn;
+            if (credit > (4u << 16)) credit = 4u << 16;
+            while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {
+                credit -= 1u << 16;
+                do_pair();
             }
             STAMP_MID
             __syncthreads();
             STAMP_END
         }
         STAMP_STORE(role)
-        __syncthreads();   // both convert waves have deposited their maxima (matched by the other roles below)
-        if (cw == 0 && laneValid) {
-            A.number_samples[vRaw] = noutLane;
-            A.max_sample[vRaw] = sMax[lane];
+        SUB_STORE(role)
+        // every tube sample is in the ring now: anything still queued needs no further hand-off
+        while (blk < nBlocks) do_pair();
+        // fold the running maxima across the 32 columns of each half: row r -> voices 32*cw + 2r (lanes
+        // 0-31) and 32*cw + 2r + 1 (lanes 32-63)
+        float myMax = 0.0f;     // collected by lanes 0..31: voice 32*cw + lane
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float m = mxTile[r * kWave + lane];
+            for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+            const float lowHalf = __shfl(m, 0, kWave), highHalf = __shfl(m, 32, kWave);
+            if (lane == 2 * r) myMax = lowHalf;
+            if (lane == 2 * r + 1) myMax = highHalf;
+        }
+        const uint32_t ov = blockIdx.x * kWave + 32 * cw + (lane & 31);
+        const uint32_t nov = __builtin_amdgcn_ds_bpermute(4 * (32 * cw + (lane & 31)), noutLane);
+        if (lane < 32 && ov < A.nvoices) {
+            A.number_samples[ov] = nov;
+            A.max_sample[ov] = myMax;
         }
         return;
     }
-    __syncthreads();       // pairs with the convert waves' final barrier
 }
 
 // Output normalisation (TRMTubeModel.m:370-389 file path, :515-533 WAV-data path).  One
