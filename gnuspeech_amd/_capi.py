@@ -50,6 +50,7 @@ EXPORTS = [
     "trm_tube_number_samples", "trm_tube_maximum_sample_value", "trm_tube_samples",
     "trm_tube_save_output_to_file", "trm_tube_generate_wav_data",
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
+    "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
     "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info",
 ]
@@ -105,6 +106,9 @@ def lib():
     L.trm_batch_derived.argtypes = [vp, C.POINTER(TrmDerived)]
     L.trm_batch_samples_for_frames.argtypes = [vp, C.c_size_t]
     L.trm_batch_samples_for_frames.restype = C.c_size_t
+    L.trm_derive.argtypes = [C.POINTER(TrmInputParams), C.POINTER(TrmDerived)]
+    L.trm_samples_for_frames.argtypes = [C.POINTER(TrmInputParams), C.c_size_t]
+    L.trm_samples_for_frames.restype = C.c_size_t
     L.trm_batch_synthesize_host.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]

@@ -70,6 +70,9 @@ struct trm_batch {
     hipStream_t stream = nullptr;        // used by the host-buffer entry points
     trm::Const *dConst = nullptr;
     float *dRowsAlloc = nullptr, *dRows = nullptr, *dSine = nullptr;
+    float *dFine = nullptr;              // down-sampling batches only
+    DevBuf<float> dTube;                 // down-sampling: tube-rate samples between the two kernels
+    DevBuf<uint64_t> dTubeOff;
     DevBuf<float> dNoise;
     double *dNoiseState = nullptr;
     uint32_t noiseLen = 0;
@@ -136,9 +139,6 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     }
     if (c.controlPeriod < 4)
         return fail(TRM_ERANGE, "control period of %d tube samples is below the kernel's pipeline step", c.controlPeriod);
-    if (!c.upsample)
-        return fail(TRM_ERANGE, "tube rate %d Hz above the output rate %g Hz: the down-sampling converter branch "
-                                "(TRMSampleRateConverter.m:234-297) is not on the HIP path yet", d.sampleRate, (double)params->outputRate);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TRM_ENODEVICE, "no HIP device visible");
     if (device < 0) {
@@ -177,6 +177,12 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipMalloc((void **)&b->dSine, sine.size() * sizeof(float)));
     B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dNoiseState, 2 * sizeof(double)));
+    if (!c.upsample) {
+        std::vector<float> fine;
+        trm::build_src_fine(fine);
+        B_TRY(hipMalloc((void **)&b->dFine, fine.size() * sizeof(float)));
+        B_TRY(hipMemcpy(b->dFine, fine.data(), fine.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
 #undef B_TRY
     *out = b;
     return TRM_OK;
@@ -190,6 +196,7 @@ void trm_batch_destroy(trm_batch *b)
     if (b->dConst) (void)hipFree(b->dConst);
     if (b->dRowsAlloc) (void)hipFree(b->dRowsAlloc);
     if (b->dSine) (void)hipFree(b->dSine);
+    if (b->dFine) (void)hipFree(b->dFine);
     if (b->dNoiseState) (void)hipFree(b->dNoiseState);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -206,6 +213,22 @@ size_t trm_batch_samples_for_frames(const trm_batch *b, size_t nframes)
 {
     if (!b || nframes == 0) return 0;                                   // TRMTubeModel.m:274-277
     return (size_t)trm::count_outputs(b->d, (uint64_t)(nframes - 1) * (uint64_t)b->d.controlPeriod);
+}
+
+int trm_derive(const trm_input_params *params, trm_derived *out)
+{
+    if (!params || !out) return fail(TRM_EINVAL, "null argument");
+    trm::Const c;
+    int rc = trm::build_const(*params, c, *out);
+    if (rc) return fail(rc, "%s", trm_strerror(rc));
+    return TRM_OK;
+}
+
+size_t trm_samples_for_frames(const trm_input_params *params, size_t nframes)
+{
+    trm_derived d;
+    if (nframes == 0 || trm_derive(params, &d) != TRM_OK) return 0;
+    return (size_t)trm::count_outputs(d, (uint64_t)(nframes - 1) * (uint64_t)d.controlPeriod);
 }
 
 // The voice-independent noise sequence is generated on the device (fp64, one lane) and cached;
@@ -262,6 +285,20 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     a.sine = b->dSine;
     a.nvoices = (uint32_t)nvoices;
     a.stamps = nullptr;
+    a.tube_out = nullptr;
+    a.tube_offset = nullptr;
+    if (!b->c.upsample) {
+        // tube rate above the output rate: tube-rate samples go through HBM to the down-sampling kernel;
+        // voice v gets a fixed-pitch row of (max_nframes-1)*controlPeriod + 2*pad floats
+        const uint64_t pitch = ntubeMax + 2ull * (uint64_t)b->d.padSize;
+        if ((rc = b->dTube.reserve(pitch * nvoices + 1)) || (rc = b->dTubeOff.reserve(nvoices))) return rc;
+        std::vector<uint64_t> offs(nvoices);
+        for (size_t i = 0; i < nvoices; i++) offs[i] = pitch * i;
+        HIP_TRY(hipMemcpyAsync(b->dTubeOff.p, offs.data(), nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));      // offs is a stack temporary
+        a.tube_out = b->dTube.p;
+        a.tube_offset = b->dTubeOff.p;
+    }
 #ifdef TRM_STAMP
     {   // diagnostic library only: per-workgroup, per-role {work, wait} cycle sums; read back with
         // trm_batch_noise_table-like copy in tools/stage_profile.py via TRM_STAMP_PTR
@@ -279,6 +316,19 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         HIP_TRY(hipEventRecord(e0, stream));
     }
     HIP_TRY(trm::launch_tube(b->c, a, stream));
+    if (!b->c.upsample) {
+        trm::DownArgs d;
+        d.tube = b->dTube.p;
+        d.tube_offset = b->dTubeOff.p;
+        d.nframes = d_nframes;
+        d.out = d_out;
+        d.out_offset = d_out_offset;
+        d.number_samples = d_number_samples;
+        d.max_sample = d_max_sample;
+        d.fine = b->dFine;
+        d.nvoices = (uint32_t)nvoices;
+        HIP_TRY(trm::launch_downsample(b->c, d, stream));
+    }
     if (b->timing) {
         HIP_TRY(hipEventRecord(e1, stream));
         b->events.emplace_back(e0, e1);

@@ -25,6 +25,11 @@ struct TubeArgs {
     const float *lp_noise;
     const float *src_rows;
     const float *sine;
+    // down-sampling batches only (tube rate above the output rate): the tube stage writes its tube-rate
+    // samples here (voice v at tube_out + tube_offset[v], ntube[v] + 2*pad floats incl. the zero flush) and
+    // trm_downsample_kernel converts them; null otherwise
+    float *tube_out;
+    const uint64_t *tube_offset;
     uint32_t nvoices;
     unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product
 };
@@ -43,6 +48,19 @@ struct ScaleArgs {
 
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
+// Down-sampling converter (TRMSampleRateConverter.m:234-297) over tube-rate samples in HBM.
+struct DownArgs {
+    const float *tube;            // tube-rate samples incl. 2*pad zeros of flush per voice
+    const uint64_t *tube_offset;
+    const uint32_t *nframes;
+    float *out;
+    const uint64_t *out_offset;
+    uint32_t *number_samples;
+    float *max_sample;
+    const float *fine;            // fine[q] = h[q>>8] + deltaH[q>>8]*(q&255)/256, q < 3328*256
+    uint32_t nvoices;
+};
+hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
 
 }  // namespace trm

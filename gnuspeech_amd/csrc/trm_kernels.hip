@@ -272,6 +272,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         TubeState S;
         tube_reset(S);
         float *const ring = &sY[lane * kYStride];
+        // down-sampling batches: tube-rate samples (and the zero flush) go to HBM for trm_downsample_kernel
+        float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
                         ring[slot] = y;
                         if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;   // mirror: windows never wrap
+                        if (tubeOut && laneValid && n < ntubeLane + 2u * (uint32_t)C.padSize) tubeOut[n] = y;
                     }
                 }
             }
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v]);
         const uint32_t myLo = (uint32_t)myOut, myHi = (uint32_t)(myOut >> 32);
         const uint32_t noutMax = wave_max_u32(noutLane);
-        const uint32_t nBlocks = (noutMax + kCvtCols - 1) / kCvtCols;
+        // (a down-sampling batch is converted by trm_downsample_kernel: no blocks here, only the barriers)
+        const uint32_t nBlocks = C.upsample ? (noutMax + kCvtCols - 1) / kCvtCols : 0;
         const int col = lane & (kCvtCols - 1);      // output within the block
         const bool upper = lane >= kCvtCols;        // which of a row's two voices
         auto pick = [&](uint32_t x, int voiceEven) {   // x of voice voiceEven (lanes 0-31) / voiceEven+1 (lanes 32-63)
@@ -439,11 +443,53 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         }
         const uint32_t ov = blockIdx.x * kWave + 32 * cw + (lane & 31);
         const uint32_t nov = __builtin_amdgcn_ds_bpermute(4 * (32 * cw + (lane & 31)), noutLane);
-        if (lane < 32 && ov < A.nvoices) {
+        if (lane < 32 && ov < A.nvoices && C.upsample) {
             A.number_samples[ov] = nov;
             A.max_sample[ov] = myMax;
         }
         return;
+    }
+}
+
+// Down-sampling branch of the converter (TRMSampleRateConverter.m:234-297): one workgroup per voice,
+// one thread per output sample.  Output k sits at input time k*inc (16.16, inc > 2^16); both wings walk
+// the impulse response at phaseIncrement per tap (:246-270).  The converter's ring index e corresponds
+// to tube sample e - pad (TRMRingBuffer.m:36-37); samples outside [0, ntube) are zero.
+__global__ __launch_bounds__(256) void trm_downsample_kernel(const Const C, const DownArgs D)
+{
+    const uint32_t v = blockIdx.x;
+    const uint32_t nfr = D.nframes[v];
+    const uint32_t pad = (uint32_t)C.padSize;
+    const uint32_t ntube = nfr > 0 ? (nfr - 1) * (uint32_t)C.controlPeriod : 0;
+    const uint32_t inc = C.timeRegisterIncrement;
+    uint32_t nout = 0;
+    if (nfr > 0) nout = (uint32_t)((((uint64_t)ntube + 2ull * pad) * 65536ull + inc - 1) / inc);
+    const float *x = D.tube + D.tube_offset[v];
+    float *out = D.out + D.out_offset[v];
+    auto sample = [&](int64_t n) { return (n >= 0 && n < (int64_t)ntube) ? x[n] : 0.0f; };
+    float m = 0.0f;
+    for (uint32_t k = threadIdx.x; k < nout; k += blockDim.x) {
+        const uint64_t tk = (uint64_t)k * inc;
+        const int64_t e = (int64_t)(tk >> 16);
+        const uint32_t frac = (uint32_t)(tk & 0xFFFFu);
+        float acc = 0.0f;
+        uint32_t ph = (uint32_t)__builtin_rint((double)frac * C.sampleRateRatioD);          // :243
+        for (int64_t n = e - pad; (ph >> 8) < 3328u; n--, ph += C.phaseIncrement) acc += sample(n) * D.fine[ph];
+        ph = (uint32_t)__builtin_rint((double)((~frac) & 0xFFFFu) * C.sampleRateRatioD);     // :257
+        for (int64_t n = e + 1 - pad; (ph >> 8) < 3328u; n++, ph += C.phaseIncrement) acc += sample(n) * D.fine[ph];
+        out[k] = acc;
+        m = fmaxf(m, fabsf(acc));
+    }
+    __shared__ float sM[256];
+    sM[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sM[threadIdx.x] = fmaxf(sM[threadIdx.x], sM[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        D.number_samples[v] = nout;
+        D.max_sample[v] = sM[0];
     }
 }
 
@@ -485,6 +531,13 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kWave - 1) / kWave;
     hipLaunchKernelGGL(trm_tube_kernel, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream)
+{
+    if (a.nvoices == 0) return hipSuccess;
+    hipLaunchKernelGGL(trm_downsample_kernel, dim3(a.nvoices), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }
 

@@ -157,6 +157,9 @@ int  trm_batch_derived(const trm_batch *batch, trm_derived *out);
 
 /* Output samples a voice of `nframes` frames produces (exact, integer-only). */
 size_t trm_batch_samples_for_frames(const trm_batch *batch, size_t nframes);
+/* Same, and the derived constants, without a device (sizing / sharding on hosts that only plan). */
+int    trm_derive(const trm_input_params *params, trm_derived *out);
+size_t trm_samples_for_frames(const trm_input_params *params, size_t nframes);
 
 /* Host-buffer form: frames = concatenated rows, voice v owns rows
  * [frame_offset[v], frame_offset[v]+nframes[v]); out receives voice v's fp32 PCM at

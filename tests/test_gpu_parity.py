@@ -18,7 +18,7 @@ RMS_TOL = 1e-5
 # fp32 waveguide's rounding noise is amplified by the resonance (measured 2.1e-5 with the identical
 # arithmetic on the host, 4e-6 with an fp64 waveguide).  Speech-like tracks sit at ~1e-6.
 STRESS_TOL = {"monet_vowel_44k": 4e-5, "monet_vowel_22k": 4e-5}
-UPSAMPLING_CASES = [n for n in golden_io.CASE_NAMES if n != "short_tube_downsample"]
+ALL_CASES = list(golden_io.CASE_NAMES)      # incl. short_tube_downsample: the converter's down-sampling branch
 
 
 def nrms(x, ref, mx):
@@ -34,7 +34,7 @@ def g():
     return gnuspeech_amd
 
 
-@pytest.mark.parametrize("name", UPSAMPLING_CASES)
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_tube_model_matches_reference_fixture(g, name):
     """TRMTubeModel -initWithInputData: / -synthesize on the GPU vs what the reference's C tube produced."""
     gold = golden_io.load(name)
@@ -106,6 +106,17 @@ def test_batch_ragged_config4(g):
     rows = cases.load_gnuspeech_rows()
     voices += [np.zeros((0, 16)), rows[5:6].copy(), rows[100:102].copy(), rows[0:130].copy()]
     _batch_vs_oracle(g, cases.monet_default_params(22050.0), voices)
+
+
+def test_downsampling_batch(g):
+    """Tube rate above the output rate (short tubes, 22.05 kHz): TRMSampleRateConverter.m:234-297 on the GPU,
+    ragged voices, against the oracle."""
+    rows = cases.load_gnuspeech_rows()
+    pd = cases.monet_default_params(22050.0)
+    pd["length"] = 12.5                                                 # "LgChild" voice, Other/voices.config
+    voices = [rows[100:130].copy(), rows[10:70].copy(), rows[200:203].copy(), np.zeros((0, 16)), rows[0:1].copy()]
+    voices += [rows[i:i + 20].copy() for i in range(0, 300, 5)]          # 60 more: spans two workgroups
+    _batch_vs_oracle(g, pd, voices)
 
 
 def test_tract_defaults_and_sine(g):
