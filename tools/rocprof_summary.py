@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel stats + optional PMC passes) into one small text file for profiles/.
+
+usage: rocprof_summary.py <out.txt> <kernel_trace_dir> [<pmc_dir> ...]"""
+import collections
+import csv
+import glob
+import sys
+
+
+def main():
+    out, trace_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    lines = []
+    for f in glob.glob(trace_dir + "/**/*_kernel_stats.csv", recursive=True):
+        lines.append("== rocprofv3 --kernel-trace --stats (%s)" % f)
+        lines += [ln.rstrip() for ln in open(f)]
+    for f in glob.glob(trace_dir + "/**/*_kernel_trace.csv", recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if "trm_tube_kernel" in r["Kernel_Name"]]
+        if rows:
+            r = rows[-1]
+            lines.append("== last trm_tube_kernel dispatch: grid %s wg %s VGPR %s SGPR %s LDS %s scratch %s" % (
+                r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("SGPR_Count"),
+                r.get("LDS_Block_Size"), r.get("Scratch_Size")))
+            d = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows]
+            lines.append("   dispatch durations ns: n=%d min=%d median=%d max=%d" % (len(d), min(d), sorted(d)[len(d) // 2], max(d)))
+    for pd in pmc_dirs:
+        for f in glob.glob(pd + "/**/*_counter_collection.csv", recursive=True):
+            agg = collections.defaultdict(float)
+            for r in csv.DictReader(open(f)):
+                if "trm_tube_kernel" in r["Kernel_Name"]:
+                    agg[(int(r["Dispatch_Id"]), r["Counter_Name"])] += float(r["Counter_Value"])
+            if not agg:
+                continue
+            last = max(k[0] for k in agg)
+            lines.append("== rocprofv3 --pmc (%s), last trm_tube_kernel dispatch (id %d), summed over XCDs/SEs" % (f, last))
+            for (d, name), v in sorted(agg.items()):
+                if d == last:
+                    lines.append("   %-28s %.6g" % (name, v))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
