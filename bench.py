@@ -118,6 +118,16 @@ def main():
     alg_bytes = 4.0 * samples_per_step_rank + 64.0 * a.voices * nframes
     avg_launch_s = (kern_ms / max(1, launches)) * 1e-3
     achieved = alg_bytes / avg_launch_s / 1e9
+    # HBM bytes per launch from the PMC passes kept under profiles/ (collected separately: --pmc cannot be
+    # combined with the timed run); only quoted when it was measured on this very workload
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        w = tj["workload"]
+        if (w["voices_per_gpu"], w["frames_per_voice"], w["kind"]) == (a.voices, nframes, a.workload):
+            traffic = tj["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "audio samples/s (whole node) + concurrent real-time tube voices",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -128,7 +138,7 @@ def main():
                    "output_samples_per_voice": samples_per_step_rank // max(1, a.voices),
                    "tube_rate_hz": b.derived["sampleRate"], "control_rate_hz": 250, "sharding": "voices, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "trm_tube_kernel", "avg_launch_ms": kern_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "VALU-issue bound scalar recurrence (SURVEY 8d); HBM-write fraction reported as BASELINE asks"},
