@@ -58,8 +58,7 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 // tracked by vmcnt; the compiler does not know these writes, so readers wait explicitly.
 typedef __attribute__((address_space(1))) const void *GlobalPtr;
 typedef __attribute__((address_space(3))) void *LdsPtr;
-// 16-byte vector with 4-byte alignment: PCM rows start at arbitrary sample offsets
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));   // two-wide fp32: v_pk_fma_f32 / v_pk_mul_f32
 
 __device__ __forceinline__ void dma16(const float *src, float *ldsBaseUniform)
 {
@@ -134,6 +133,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // excitation per sample
     __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * 6 * kWave];      // coefficients per sample
     __shared__ __attribute__((aligned(16))) float sY[kWave * kYStride];          // tube-rate rings
+    __shared__ uint4 sInfo[kWave];                                               // convert: {length, ptr lo, ptr hi} per voice
     __shared__ float sMx[2 * 16 * kWave];                                        // convert: running max |y| per (row, lane)
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
     __shared__ float sFir[32];                                                   // excite: FIR taps
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     // wave -> role.  A workgroup's waves are dealt to the CU's 4 SIMDs in turn, so waves w and w+4 share
     // one SIMD's issue slots: TRM_ROLE_PERM lists the role of each wave (diagnostic builds may override it).
 #ifndef TRM_ROLE_PERM
-#define TRM_ROLE_PERM 0, 1, 2, 3, 4, 5
+#define TRM_ROLE_PERM 4, 5, 0, 3, 1, 2   /* convert0 convert1 excite tube | coef0 coef1: measured best of five (tools/stage_profile.py) */
 #endif
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int rolePerm[kRoles] = {TRM_ROLE_PERM};
@@ -269,42 +269,48 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         STAMP_STORE(role)
     } else if (role == 3) {
         // ------------------------------------------------------------ tube
-        TubeState S;
-        tube_reset(S);
+        // two wave sets: sample 2i steps wA -> wB, sample 2i+1 steps wB -> wA (kTB == 2: no state copies)
+        Waves wA, wB;
+        TubeFilters F;
+        waves_reset(wA);
+        waves_reset(wB);
+        filters_reset(F);
         float *const ring = &sY[lane * kYStride];
         // down-sampling batches: tube-rate samples (and the zero flush) go to HBM for trm_downsample_kernel
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
+        auto one = [&](const Waves &o, Waves &nw, int buf, int u, uint32_t n) {
+            const float4 x = sX[(buf * kTB + u) * kWave + lane];
+            const float4 *src = &sK[((buf * kTB + u) * 6) * kWave + lane];
+            const float4 k0 = src[0 * kWave], k1 = src[1 * kWave], k2 = src[2 * kWave];
+            const float4 t0 = src[3 * kWave], t1 = src[4 * kWave], bp = src[5 * kWave];
+            Excitation E;
+            E.gin = x.x; E.sig = x.y; E.thr = x.z;
+            Coefs K;
+            K.k[0] = k0.x; K.k[1] = k0.y; K.k[2] = k0.z; K.k[3] = k0.w;
+            K.k[4] = k1.x; K.k[5] = k1.y; K.k[6] = k1.z; K.k[7] = k1.w;
+            K.onePlusK8 = k2.x; K.alphaLR = k2.y; K.alphaU = k2.z; K.nk1 = k2.w;
+            K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
+            K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
+            K.bpAlpha = bp.x; K.bpBeta = bp.y; K.bpGamma = bp.z; K.pad_ = 0.0f;
+            float y = tube_step(o, nw, F, C, E, K);
+            y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
+            // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
+            const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
+            ring[slot] = y;
+            if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;   // mirror: windows never wrap
+            if (tubeOut && laneValid && n < ntubeLane + 2u * (uint32_t)C.padSize) tubeOut[n] = y;
+        };
+        static_assert(kTB == 2, "the tube stage ping-pongs two wave sets per step");
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 1) {
+            if (step >= 1 && (step - 1) * kTB < nTotal) {
+                // both samples of the block are stepped even when the second one lies past nTotal (odd
+                // totals): its inputs are stale LDS contents, its output is forced to 0 and never read
                 const uint32_t blk = step - 1;
                 const int buf = blk & 1;
-                for (int u = 0; u < kTB; u++) {
-                    const uint32_t n = blk * kTB + u;
-                    if (n < nTotal) {
-                        const float4 x = sX[(buf * kTB + u) * kWave + lane];
-                        const float4 *src = &sK[((buf * kTB + u) * 6) * kWave + lane];
-                        const float4 k0 = src[0 * kWave], k1 = src[1 * kWave], k2 = src[2 * kWave];
-                        const float4 t0 = src[3 * kWave], t1 = src[4 * kWave], bp = src[5 * kWave];
-                        Excitation E;
-                        E.gin = x.x; E.sig = x.y; E.thr = x.z;
-                        Coefs K;
-                        K.k[0] = k0.x; K.k[1] = k0.y; K.k[2] = k0.z; K.k[3] = k0.w;
-                        K.k[4] = k1.x; K.k[5] = k1.y; K.k[6] = k1.z; K.k[7] = k1.w;
-                        K.onePlusK8 = k2.x; K.alphaLR = k2.y; K.alphaU = k2.z; K.nk1 = k2.w;
-                        K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
-                        K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
-                        K.bpAlpha = bp.x; K.bpBeta = bp.y; K.bpGamma = bp.z; K.pad_ = 0.0f;
-                        float y = tube_sample(S, C, E, K);
-                        y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
-                        // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
-                        const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
-                        ring[slot] = y;
-                        if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;   // mirror: windows never wrap
-                        if (tubeOut && laneValid && n < ntubeLane + 2u * (uint32_t)C.padSize) tubeOut[n] = y;
-                    }
-                }
+                one(wA, wB, buf, 0, blk * kTB);
+                one(wB, wA, buf, 1, blk * kTB + 1);
             }
             STAMP_MID
             __syncthreads();
@@ -328,11 +334,10 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         const uint32_t nBlocks = C.upsample ? (noutMax + kCvtCols - 1) / kCvtCols : 0;
         const int col = lane & (kCvtCols - 1);      // output within the block
         const bool upper = lane >= kCvtCols;        // which of a row's two voices
-        auto pick = [&](uint32_t x, int voiceEven) {   // x of voice voiceEven (lanes 0-31) / voiceEven+1 (lanes 32-63)
-            uint32_t a = __builtin_amdgcn_readlane(x, voiceEven);
-            uint32_t b = __builtin_amdgcn_readlane(x, voiceEven + 1);
-            return upper ? b : a;
-        };
+        // destination pointer and length of every voice of this wave, laid out per (row, half) so that a row's
+        // lanes fetch theirs with one broadcast ds_read_b128: {length, ptr lo, ptr hi, -}
+        uint4 *const info = &sInfo[cw * 32];
+        if (lane >= 32 * cw && lane < 32 * cw + 32) info[lane - 32 * cw] = make_uint4(noutLane, myLo, myHi, 0u);
         // running max |y| (TRMSampleRateConverter.m:206-208) per (row of this wave, lane) in LDS: row r covers
         // voice 32*cw + 2*r (+1 in the upper half); folded across the 32 columns once, at the end
         float *const mxTile = &sMx[cw * 16 * kWave];
@@ -342,7 +347,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         // full rate, narrow ones at a fraction of it): the window starts winOff = e & 3 samples early and
         // the lane's 26 coefficients are fetched shifted right by winOff.  Coefficient rows are 32 floats
         // (26 + 6 zeros) with 4 zeros in front of row 0, so the shifted fetch only ever picks up zeros.
-        float cc[32], nc[32];
+        float nc[32];
+        v2f cc[16];
         auto fetch_row = [&](uint32_t blk, float *c) {
             const uint32_t k = blk * kCvtCols + col;
             const uint32_t off = src_position(k, inc) & 3u;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             // the longest voice's end are masked, so the last block only waits for the final sample
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            for (int q = 0; q < 32; q++) cc[q] = nc[q];
+            for (int q = 0; q < 16; q++) cc[q] = v2f{nc[2 * q], nc[2 * q + 1]};
             if (blk + 1 < nBlocks) fetch_row(blk + 1, nc);          // prefetch the next block's coefficients
         };
         if (nBlocks > 0) {
@@ -383,23 +389,26 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             const int ha = upper ? 1 : 0;
             const float4 *wa = reinterpret_cast<const float4 *>(&sY[(va + ha) * kYStride + winBase]);
             const float4 *wb = reinterpret_cast<const float4 *>(&sY[(vb + ha) * kYStride + winBase]);
-            float winA[32], winB[32];
-            for (int q = 0; q < 8; q++) {
-                float4 a = wa[q], b = wb[q];
-                winA[4 * q] = a.x; winA[4 * q + 1] = a.y; winA[4 * q + 2] = a.z; winA[4 * q + 3] = a.w;
-                winB[4 * q] = b.x; winB[4 * q + 1] = b.y; winB[4 * q + 2] = b.z; winB[4 * q + 3] = b.w;
-            }
+            float4 qa[8], qb[8];
+            for (int q = 0; q < 8; q++) { qa[q] = wa[q]; qb[q] = wb[q]; }
+            const uint4 ia = info[la + ha], ib = info[lb + ha];
             SUB_LAP(0)
-            const uint32_t lenA = pick(noutLane, va), lenB = pick(noutLane, vb);
-            const uint32_t loA = pick(myLo, va), hiA = pick(myHi, va);
-            const uint32_t loB = pick(myLo, vb), hiB = pick(myHi, vb);
-            SUB_LAP(1)
-            const float ya = src_dot32(winA, cc);
-            const float yb = src_dot32(winB, cc);
+            // 32-term dot products as packed FMAs: (even, odd) partial sums, two chains per row
+            v2f a0 = v2f{qa[0].x, qa[0].y} * cc[0], a1 = v2f{qa[0].z, qa[0].w} * cc[1];
+            v2f b0 = v2f{qb[0].x, qb[0].y} * cc[0], b1 = v2f{qb[0].z, qb[0].w} * cc[1];
+            for (int q = 1; q < 8; q++) {
+                a0 = __builtin_elementwise_fma(v2f{qa[q].x, qa[q].y}, cc[2 * q], a0);
+                a1 = __builtin_elementwise_fma(v2f{qa[q].z, qa[q].w}, cc[2 * q + 1], a1);
+                b0 = __builtin_elementwise_fma(v2f{qb[q].x, qb[q].y}, cc[2 * q], b0);
+                b1 = __builtin_elementwise_fma(v2f{qb[q].z, qb[q].w}, cc[2 * q + 1], b1);
+            }
+            a0 += a1;
+            b0 += b1;
+            const float ya = a0.x + a0.y, yb = b0.x + b0.y;
             SUB_LAP(2)
-            const bool okA = kLane < lenA, okB = kLane < lenB;
-            if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiA << 32) | loA)[kLane] = ya;
-            if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)hiB << 32) | loB)[kLane] = yb;
+            const bool okA = kLane < ia.x, okB = kLane < ib.x;
+            if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ia.z << 32) | ia.y)[kLane] = ya;
+            if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ib.z << 32) | ib.y)[kLane] = yb;
             SUB_LAP(3)
             // running max |y| per (row, lane): conflict-free LDS float-max, folded across columns at the end
             __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&mxTile[(2 * pr) * kWave + lane], okA ? fabsf(ya) : 0.0f, 0, 0, false);

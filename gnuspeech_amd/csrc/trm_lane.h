@@ -346,74 +346,93 @@ TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
 }
 
 // ================================================================ stage 3: the tube recurrences
-struct TubeState {
-    // waveguide: travelling-wave values of the previous sample (TRMTubeModel.m:161-165)
+// Travelling-wave values of one sample (TRMTubeModel.m:161-165).  The reference double-buffers them
+// ([section][top|bottom][ping|pong]); here a step reads one Waves and writes another, so two
+// consecutive samples ping-pong between two register sets without copies.
+struct Waves {
     wg_t oT[10], oB[10];        // oropharynx top / bottom
     wg_t nT[6], nB[6];          // nasal
+};
+
+struct TubeFilters {
     wg_t mReflY, mRadX, mRadY;  // mouth filter memories
     wg_t nReflY, nRadX, nRadY;  // nose filter memories
     wg_t throatY;
     float bpX1, bpX2, bpY1, bpY2;   // frication band-pass memory (TRMFilters.m:19-29)
 };
 
-TRM_HD void tube_reset(TubeState &L)
+struct TubeState {
+    Waves w;
+    TubeFilters f;
+};
+
+TRM_HD void waves_reset(Waves &W)
 {
-    for (int i = 0; i < 10; i++) { L.oT[i] = 0.f; L.oB[i] = 0.f; }
-    for (int i = 0; i < 6; i++) { L.nT[i] = 0.f; L.nB[i] = 0.f; }
+    for (int i = 0; i < 10; i++) { W.oT[i] = 0.f; W.oB[i] = 0.f; }
+    for (int i = 0; i < 6; i++) { W.nT[i] = 0.f; W.nB[i] = 0.f; }
+}
+
+TRM_HD void filters_reset(TubeFilters &L)
+{
     L.mReflY = L.mRadX = L.mRadY = 0.f;
     L.nReflY = L.nRadX = L.nRadY = 0.f;
     L.throatY = 0.f;
     L.bpX1 = L.bpX2 = L.bpY1 = L.bpY2 = 0.f;
 }
 
+TRM_HD void tube_reset(TubeState &S)
+{
+    waves_reset(S.w);
+    filters_reset(S.f);
+}
+
+// One sample: old waves `o` -> new waves `nw` (all new values from old values only, :778-853).
 // Returns the tube-rate output sample (what the reference hands to -dataFill:, :346).
-TRM_HD float tube_sample(TubeState &L, const Const &C, const Excitation &E, const Coefs &K)
+TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C, const Excitation &E, const Coefs &K)
 {
     // frication band-pass (TRMFilters.m:19-29), evaluated before the tract (:336-337)
     float fric = 2.0f * fma_f(K.bpAlpha, E.sig - L.bpX2, fma_f(K.bpGamma, L.bpY1, -(K.bpBeta * L.bpY2)));
     L.bpX2 = L.bpX1; L.bpX1 = E.sig; L.bpY2 = L.bpY1; L.bpY1 = fric;
 
-    // waveguide (:778-853): all new values from old values only
     const float *k = K.k, *tap = K.tap;
     const wg_t d = C.damping;
     const wg_t input = E.gin;
     const wg_t fr = fric;
-    wg_t nOT[10], nOB[10], nNT[6], nNB[6];
-    nOT[0] = L.oB[0] * d + input;
+    nw.oT[0] = o.oB[0] * d + input;
     {
-        wg_t dl = k[0] * (L.oT[0] - L.oB[1]);
-        nOT[1] = (L.oT[0] + dl) * d;
-        nOB[0] = (L.oB[1] + dl) * d;
+        wg_t dl = k[0] * (o.oT[0] - o.oB[1]);
+        nw.oT[1] = (o.oT[0] + dl) * d;
+        nw.oB[0] = (o.oB[1] + dl) * d;
     }
     for (int i = 1; i < 3; i++) {             // S2-S3, S3-S4 with taps FC1, FC2
-        wg_t dl = k[i] * (L.oT[i] - L.oB[i + 1]);
-        nOT[i + 1] = (L.oT[i] + dl) * d + tap[i - 1] * fr;
-        nOB[i] = (L.oB[i + 1] + dl) * d;
+        wg_t dl = k[i] * (o.oT[i] - o.oB[i + 1]);
+        nw.oT[i + 1] = (o.oT[i] + dl) * d + tap[i - 1] * fr;
+        nw.oB[i] = (o.oB[i + 1] + dl) * d;
     }
     {
-        wg_t jp = K.alphaLR * L.oT[3] + (K.alphaLR * L.oB[4] + K.alphaU * L.nB[0]);
-        nOB[3] = (jp - L.oT[3]) * d;
-        nOT[4] = (jp - L.oB[4]) * d + tap[2] * fr;
-        nNT[0] = (jp - L.nB[0]) * d;
+        wg_t jp = K.alphaLR * o.oT[3] + (K.alphaLR * o.oB[4] + K.alphaU * o.nB[0]);
+        nw.oB[3] = (jp - o.oT[3]) * d;
+        nw.oT[4] = (jp - o.oB[4]) * d + tap[2] * fr;
+        nw.nT[0] = (jp - o.nB[0]) * d;
     }
     {
-        wg_t dl = k[3] * (L.oT[4] - L.oB[5]);
-        nOT[5] = (L.oT[4] + dl) * d + tap[3] * fr;
-        nOB[4] = (L.oB[5] + dl) * d;
+        wg_t dl = k[3] * (o.oT[4] - o.oB[5]);
+        nw.oT[5] = (o.oT[4] + dl) * d + tap[3] * fr;
+        nw.oB[4] = (o.oB[5] + dl) * d;
     }
-    nOT[6] = L.oT[5] * d + tap[4] * fr;
-    nOB[5] = L.oB[6] * d;
+    nw.oT[6] = o.oT[5] * d + tap[4] * fr;
+    nw.oB[5] = o.oB[6] * d;
     for (int i = 6; i < 9; i++) {             // S7-S8, S8-S9, S9-S10 with taps FC6..FC8
-        wg_t dl = k[i - 2] * (L.oT[i] - L.oB[i + 1]);
-        nOT[i + 1] = (L.oT[i] + dl) * d + tap[i - 1] * fr;
-        nOB[i] = (L.oB[i + 1] + dl) * d;
+        wg_t dl = k[i - 2] * (o.oT[i] - o.oB[i + 1]);
+        nw.oT[i + 1] = (o.oT[i] + dl) * d + tap[i - 1] * fr;
+        nw.oB[i] = (o.oB[i + 1] + dl) * d;
     }
     wg_t out;
     {   // mouth: reflection y = a10*x - b11*y1, radiation y = a20*x + a21*x1 - b21*y1 (TRMFilters.m:47-60)
-        wg_t refl = C.mA10 * (k[7] * L.oT[9]) + C.mCoeff * L.mReflY;
+        wg_t refl = C.mA10 * (k[7] * o.oT[9]) + C.mCoeff * L.mReflY;
         L.mReflY = refl;
-        nOB[9] = d * refl;
-        wg_t rin = K.onePlusK8 * L.oT[9];
+        nw.oB[9] = d * refl;
+        wg_t rin = K.onePlusK8 * o.oT[9];
         wg_t rad = C.mCoeff * (rin - L.mRadX + L.mRadY);
         L.mRadX = rin; L.mRadY = rad;
         out = rad;
@@ -421,26 +440,32 @@ TRM_HD float tube_sample(TubeState &L, const Const &C, const Excitation &E, cons
     {
         float kk[5] = {K.nk1, C.nasalK[0], C.nasalK[1], C.nasalK[2], C.nasalK[3]};
         for (int i = 0; i < 5; i++) {
-            wg_t dl = kk[i] * (L.nT[i] - L.nB[i + 1]);
-            nNT[i + 1] = (L.nT[i] + dl) * d;
-            nNB[i] = (L.nB[i + 1] + dl) * d;
+            wg_t dl = kk[i] * (o.nT[i] - o.nB[i + 1]);
+            nw.nT[i + 1] = (o.nT[i] + dl) * d;
+            nw.nB[i] = (o.nB[i + 1] + dl) * d;
         }
-        wg_t refl = C.nA10 * (C.nasalK[4] * L.nT[5]) + C.nCoeff * L.nReflY;
+        wg_t refl = C.nA10 * (C.nasalK[4] * o.nT[5]) + C.nCoeff * L.nReflY;
         L.nReflY = refl;
-        nNB[5] = d * refl;
-        wg_t rin = C.onePlusNK6 * L.nT[5];
+        nw.nB[5] = d * refl;
+        wg_t rin = C.onePlusNK6 * o.nT[5];
         wg_t rad = C.nCoeff * (rin - L.nRadX + L.nRadY);
         L.nRadX = rin; L.nRadY = rad;
         out += rad;
     }
-    for (int i = 0; i < 10; i++) { L.oT[i] = nOT[i]; L.oB[i] = nOB[i]; }
-    for (int i = 0; i < 6; i++) { L.nT[i] = nNT[i]; L.nB[i] = nNB[i]; }
-
     // throat (:341, TRMFilters.m:72-77)
     wg_t ty = C.ta0 * E.thr + C.tb1 * L.throatY;
     L.throatY = ty;
     out = ty * C.throatGain + out;
     return (float)out;
+}
+
+// Single-sample form (host emulation): step into a scratch set, then commit.
+TRM_HD float tube_sample(TubeState &S, const Const &C, const Excitation &E, const Coefs &K)
+{
+    Waves nw;
+    float y = tube_step(S.w, nw, S.f, C, E, K);
+    S.w = nw;
+    return y;
 }
 
 // ================================================================ stage 4: sample-rate conversion
