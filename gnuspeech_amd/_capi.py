@@ -52,7 +52,7 @@ EXPORTS = [
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
-    "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info",
+    "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu",
 ]
 
 _lib = None

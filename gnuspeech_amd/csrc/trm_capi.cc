@@ -123,6 +123,8 @@ int trm_device_count(void)
 
 const char *trm_build_info(void) { return "libtrm_hip gfx950 (one tube per lane, wave64) " __DATE__; }
 
+int trm_kernel_blocks_per_cu(void) { return trm::tube_kernel_blocks_per_cu(); }
+
 void trm_free(void *p) { free(p); }
 
 // ------------------------------------------------------------------ batch object

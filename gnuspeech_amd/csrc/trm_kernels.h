@@ -46,6 +46,7 @@ struct ScaleArgs {
     int32_t forWavData;
 };
 
+int tube_kernel_blocks_per_cu();
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
 // Down-sampling converter (TRMSampleRateConverter.m:234-297) over tube-rate samples in HBM.

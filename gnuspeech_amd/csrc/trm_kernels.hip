@@ -136,8 +136,6 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     __shared__ uint4 sInfo[kWave];                                               // convert: {length, ptr lo, ptr hi} per voice
     __shared__ float sMx[2 * 16 * kWave];                                        // convert: running max |y| per (row, lane)
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
-    __shared__ float sFir[32];                                                   // excite: FIR taps
-    __shared__ float sSine[kTableLen];                                           // excite: sine table
 
     const int lane = threadIdx.x & (kWave - 1);
     // wave -> role.  A workgroup's waves are dealt to the CU's 4 SIMDs in turn, so waves w and w+4 share
@@ -164,7 +162,6 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
     // Output rows (64 lanes) a step's kTB tube samples turn into: kTB * 2^16/inc; the convert waves get
     // strictly more than that per step, in row pairs, split between the two waves.
-    const uint32_t rowsPerStep = (kTB * 65536u) / inc + 1;
     // the last tube block is written at step ceil(nTotal/kTB), readable one step later; the convert waves
     // are never more than one block (16 pairs, 8 per wave) behind
     // (8 row pairs per wave per block, metered at just over the production rate: a block takes about as
@@ -179,9 +176,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
 
     if (role == 0) {
         // ------------------------------------------------------------ excite
-        if (C.waveform != 0)
-            for (int i = lane; i < kTableLen; i += kWave) sSine[i] = A.sine[i];
-        auto sine = [&](int i) { return sSine[i]; };
+        auto sine = [&](int i) { return sine_table(i); };
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
             dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
         };
@@ -190,9 +185,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         excite_reset(S);
         // The 25 distinct FIR taps live in VGPRs of this wave (uniform values): as SGPRs they would
         // exceed the scalar file together with the other constants and be spilled to VGPR lanes.
-        for (int i = lane; i < kFirUnique; i += kWave) sFir[i] = C.fir[i];
         float firv[kFirUnique];
-        for (int i = 0; i < kFirUnique; i++) firv[i] = sFir[i];
+        for (int i = 0; i < kFirUnique; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(firv[i]) : "s"(C.fir[i]));
         float cur[4], prev[4];
         if (nSteps > 0) {
             load_frame(frames, 0, cur, 1);
@@ -347,13 +341,13 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         // full rate, narrow ones at a fraction of it): the window starts winOff = e & 3 samples early and
         // the lane's 26 coefficients are fetched shifted right by winOff.  Coefficient rows are 32 floats
         // (26 + 6 zeros) with 4 zeros in front of row 0, so the shifted fetch only ever picks up zeros.
-        float nc[32];
         v2f cc[16];
-        auto fetch_row = [&](uint32_t blk, float *c) {
+        auto fetch_row = [&](uint32_t blk) {
             const uint32_t k = blk * kCvtCols + col;
             const uint32_t off = src_position(k, inc) & 3u;
             const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
-            for (int q = 0; q < 32; q++) c[q] = pc[q];
+            // (the loads land while the wave idles until its next metered pair)
+            for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
         };
         uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..7) of block `blk`: voices 32*cw + 4*pr .. +3
         uint32_t winBase = 0;           // this lane's aligned window start inside a voice's ring (floats)
@@ -366,13 +360,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             // the longest voice's end are masked, so the last block only waits for the final sample
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            for (int q = 0; q < 16; q++) cc[q] = v2f{nc[2 * q], nc[2 * q + 1]};
-            if (blk + 1 < nBlocks) fetch_row(blk + 1, nc);          // prefetch the next block's coefficients
+            fetch_row(blk);
         };
-        if (nBlocks > 0) {
-            fetch_row(0, nc);
-            begin_block();
-        }
+        if (nBlocks > 0) begin_block();
         typedef __attribute__((address_space(1))) float *GlobalFloatPtr;
         typedef __attribute__((address_space(3))) float *LdsFloatPtr;
         // Work is metered so that it spreads evenly over the steps: each step earns `earn` (16.16) row pairs,
@@ -541,6 +531,14 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
     uint32_t grid = (a.nvoices + kWave - 1) / kWave;
     hipLaunchKernelGGL(trm_tube_kernel, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
     return hipGetLastError();
+}
+
+// resident workgroups of trm_tube_kernel per CU as the runtime computes it (diagnostics / DESIGN.md)
+int tube_kernel_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel, kWave * kRoles, 0) != hipSuccess) return -1;
+    return n;
 }
 
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream)

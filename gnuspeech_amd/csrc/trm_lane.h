@@ -159,6 +159,19 @@ TRM_HD void excite_track_setup(ExciteTrack &T, const Const &C, const float *prev
     T.aspDelta = (cur[2] - prev[2]) * C.invControlPeriod;
 }
 
+// Entry i of the 512-entry sine table (TRMWavetable.m:98-101), computed instead of stored: sin(2*pi*i/512)
+// by quadrant folding onto the [0, pi/4] polynomials (error < 1e-7, the table itself is fp32 here).
+TRM_HD float sine_table(int i)
+{
+    int q = i & 127;                       // position inside the quadrant
+    int quad = (i >> 7) & 3;
+    int m = (quad & 1) ? 128 - q : q;      // odd quadrants run backwards
+    bool useCos = m > 64;                  // fold [pi/4, pi/2] onto cos of the complement
+    float y = (float)(useCos ? 128 - m : m) * (6.28318530717959f / 512.0f);
+    float v = useCos ? cos_q(y) : sin_q(y);
+    return quad >= 2 ? -v : v;
+}
+
 // dB -> linear amplitude with the reference's clamps (TRMUtility.m:26-41), fp32.
 TRM_HD float amplitude_f(float db)
 {

@@ -199,6 +199,8 @@ int  trm_batch_noise_table(trm_batch *batch, float *host_out, size_t n);
 /* Library / device identification. */
 int  trm_device_count(void);
 const char *trm_build_info(void);
+/* Diagnostic: resident workgroups (64 voices each) of the tube kernel per CU, per the HIP occupancy query. */
+int  trm_kernel_blocks_per_cu(void);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
     }
     ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS;
     excite_reset(ES); tube_reset(TS);
-    auto sineLookup = [&](int i) { return sine[i]; };
+    auto sineLookup = [&](int i) { return sine_table(i); };
     // tube-rate signal, with the converter's 25 zeros of pre-roll and 2*pad zeros of flush around it
     std::vector<float> sig(25 + ntube + 2 * C.padSize, 0.0f);
     size_t n = 0;
