@@ -23,7 +23,7 @@
 namespace trm {
 
 constexpr int kWave = 64;
-constexpr int kRoles = 6;            // waves per workgroup: excite, coef x2, tube, convert x2
+constexpr int kRoles = 7;            // waves per workgroup: osc, mix, coef x2, tube, convert x2
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
 constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
 constexpr int kNoiseHalf = 64;
@@ -130,7 +130,8 @@ __device__ __forceinline__ void load_frame(const float *frames, uint32_t fi, flo
 //     rows per step keeps them ahead of production.
 __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // excitation per sample
+    __shared__ __attribute__((aligned(16))) float4 sW[2 * kTB * kWave];          // osc -> mix: {wa, wb, ax, ah1}
+    __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // mix -> tube: excitation per sample
     __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * 6 * kWave];      // coefficients per sample
     __shared__ __attribute__((aligned(16))) float sY[kWave * kYStride];          // tube-rate rings
     __shared__ uint4 sInfo[kWave];                                               // convert: {length, ptr lo, ptr hi} per voice
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     // wave -> role.  A workgroup's waves are dealt to the CU's 4 SIMDs in turn, so waves w and w+4 share
     // one SIMD's issue slots: TRM_ROLE_PERM lists the role of each wave (diagnostic builds may override it).
 #ifndef TRM_ROLE_PERM
-#define TRM_ROLE_PERM 4, 5, 0, 3, 1, 2   /* convert0 convert1 excite tube | coef0 coef1: measured best of five (tools/stage_profile.py) */
+#define TRM_ROLE_PERM 5, 6, 0, 4, 2, 3, 1   /* convert0 convert1 osc tube | coef0 coef1 mix */
 #endif
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int rolePerm[kRoles] = {TRM_ROLE_PERM};
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     // are never more than one block (16 pairs, 8 per wave) behind
     // (8 row pairs per wave per block, metered at just over the production rate: a block takes about as
     // long as the 32*inc/2^16 tube samples it spans)
-    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 2 + 2 * ((kCvtCols * inc / 65536u) / kTB + 2) + 4 : 0;
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 3 + 2 * ((kCvtCols * inc / 65536u) / kTB + 2) + 4 : 0;
     // a voice without frames (a silent no-op, TRMTubeModel.m:274-277) reads row 0 of the buffer
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
@@ -175,25 +176,13 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     __syncthreads();
 
     if (role == 0) {
-        // ------------------------------------------------------------ excite
+        // ------------------------------------------------------------ osc: tracks + oscillator, block i at step i
         auto sine = [&](int i) { return sine_table(i); };
-        auto fill_noise_half = [&](uint32_t nFirst, int half) {
-            dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
-        };
-        ExciteState S;
+        OscState S;
         ExciteTrack T;
-        excite_reset(S);
-        // The 25 distinct FIR taps live in VGPRs of this wave (uniform values): as SGPRs they would
-        // exceed the scalar file together with the other constants and be spilled to VGPR lanes.
-        float firv[kFirUnique];
-        for (int i = 0; i < kFirUnique; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(firv[i]) : "s"(C.fir[i]));
+        S.oscPos = 0.0;
         float cur[4], prev[4];
-        if (nSteps > 0) {
-            load_frame(frames, 0, cur, 1);
-            fill_noise_half(0, 0);
-            fill_noise_half(kNoiseHalf, 1);
-            dma_wait_all();
-        }
+        if (nSteps > 0) load_frame(frames, 0, cur, 1);
         uint32_t j = CP, f = 0;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
@@ -209,14 +198,52 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 1);
                         excite_track_setup(T, C, prev, cur);
                     }
-                    if ((n & (kNoiseHalf - 1)) == 0 && n > 0) {
-                        // entering a noise half: it was requested one half ago; refill the other half
-                        dma_wait_all();
-                        fill_noise_half(n + kNoiseHalf, ((n / kNoiseHalf) + 1) & 1);
-                    }
-                    Excitation E = excite_sample(S, T, C, firv, (int)j, sNoise[n & (kNoiseRing - 1)], sine);
+                    OscOut O = osc_sample(S, T, C, (int)j, sine);
                     j++;
-                    sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                    sW[(buf * kTB + u) * kWave + lane] = make_float4(O.wa, O.wb, O.ax, O.ah1);
+                }
+            }
+            STAMP_MID
+            __syncthreads();
+            STAMP_END
+        }
+        STAMP_STORE(role)
+    } else if (role == 1) {
+        // ------------------------------------------------------------ mix: FIR + noise mixing, block i-1 at step i
+        auto fill_noise_half = [&](uint32_t nFirst, int half) {
+            dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
+        };
+        FirState S;
+        for (int i = 0; i < 24; i++) S.fir[i] = 0.f;
+        // The 25 distinct FIR taps live in VGPRs of this wave (uniform values): as SGPRs they would
+        // exceed the scalar file together with the other constants and be spilled to VGPR lanes.
+        float firv[kFirUnique];
+        for (int i = 0; i < kFirUnique; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(firv[i]) : "s"(C.fir[i]));
+        if (nSteps > 0) {
+            fill_noise_half(0, 0);
+            fill_noise_half(kNoiseHalf, 1);
+            dma_wait_all();
+        }
+        STAMP_DECL
+        for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
+            if (step >= 1) {
+                const uint32_t blk = step - 1;
+                const int buf = blk & 1;
+                for (int u = 0; u < kTB; u++) {
+                    const uint32_t n = blk * kTB + u;
+                    if (n < nTotal) {
+                        if ((n & (kNoiseHalf - 1)) == 0 && n > 0) {
+                            // entering a noise half: it was requested one half ago; refill the other half
+                            dma_wait_all();
+                            fill_noise_half(n + kNoiseHalf, ((n / kNoiseHalf) + 1) & 1);
+                        }
+                        const float4 w = sW[(buf * kTB + u) * kWave + lane];
+                        OscOut O;
+                        O.wa = w.x; O.wb = w.y; O.ax = w.z; O.ah1 = w.w;
+                        Excitation E = mix_sample(S, C, firv, O, sNoise[n & (kNoiseRing - 1)]);
+                        sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                    }
                 }
             }
             STAMP_MID
@@ -225,9 +252,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         }
         STAMP_STORE(role)
         dma_wait_all();   // nothing may still be writing LDS when the wave ends
-    } else if (role == 1 || role == 2) {
-        // ------------------------------------------------------------ coef (this wave: samples of parity u)
-        const int u = role - 1;
+    } else if (role == 2 || role == 3) {
+        // ------------------------------------------------------------ coef (this wave: samples of parity u), block i-1 at step i
+        const int u = role - 2;
         CoefTrack T;
         float cur[16], prev[16];
         if (nSteps > 0) load_frame(frames, 0, cur, 4);
@@ -236,9 +263,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            const int buf = step & 1;
-            const uint32_t n = step * kTB + u;
-            if (n < nTotal) {
+            const int buf = (step + 1) & 1;             // == (step - 1) & 1
+            const uint32_t n = (step - 1) * kTB + u;    // step 0: wraps past nTotal, no work
+            if (step >= 1 && n < nTotal) {
                 if (j >= CP) {      // the host guarantees CP >= 2*kTB: at most one period boundary per step
                     j -= CP;
                     f++;
@@ -261,8 +288,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             STAMP_END
         }
         STAMP_STORE(role)
-    } else if (role == 3) {
-        // ------------------------------------------------------------ tube
+    } else if (role == 4) {
+        // ------------------------------------------------------------ tube: block i-2 at step i
         // two wave sets: sample 2i steps wA -> wB, sample 2i+1 steps wB -> wA (kTB == 2: no state copies)
         Waves wA, wB;
         TubeFilters F;
@@ -298,10 +325,10 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 1 && (step - 1) * kTB < nTotal) {
+            if (step >= 2 && (step - 2) * kTB < nTotal) {
                 // both samples of the block are stepped even when the second one lies past nTotal (odd
                 // totals): its inputs are stale LDS contents, its output is forced to 0 and never read
-                const uint32_t blk = step - 1;
+                const uint32_t blk = step - 2;
                 const int buf = blk & 1;
                 one(wA, wB, buf, 0, blk * kTB);
                 one(wB, wA, buf, 1, blk * kTB + 1);
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         STAMP_STORE(role)
     } else {
         // ------------------------------------------------------------ convert (lane = output time)
-        const int cw = role - 4;                    // this wave converts voices 32*cw .. 32*cw+31
+        const int cw = role - 5;                    // this wave converts voices 32*cw .. 32*cw+31
         uint32_t noutLane = 0;
         if (nfr > 0) {
             uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
@@ -413,8 +440,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            // visible after the previous barrier: tube samples n < (step-1)*kTB
-            const uint32_t ready = step >= 1 ? (step - 1) * kTB : 0;
+            // visible after the previous barrier: tube samples n < (step-2)*kTB
+            const uint32_t ready = step >= 2 ? (step - 2) * kTB : 0;
             credit += earn;
             if (credit > (4u << 16)) credit = 4u << 16;
             while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {

@@ -192,56 +192,77 @@ TRM_HD float pulse_table(int i, const Const &C, int newDiv2, float invFall)
     return i < C.tableDiv1 ? rise : v;
 }
 
-// `fir` = C.fir (the caller decides where the taps live), `j` = position in the control period
-// (uniform), `lpNoise` = the voice-independent low-passed noise sample (uniform), `sineTab` = 512-entry
-// sine table lookup.
+// The excitation stage in two halves (they may run in different waves):
+//   osc_sample  control tracks + 2x oversampled wavetable oscillator -> the two table reads of the
+//               sample and the two amplitudes                              (fp64 tracks live here)
+//   mix_sample  49-tap FIR + noise mixing -> Excitation                    (FIR state lives here)
+struct OscOut {
+    float wa, wb;               // the two oversampled wavetable reads (TRMWavetable.m:178-190)
+    float ax, ah1;              // amplitude(glotVol), amplitude(aspVol) (TRMTubeModel.m:295-296)
+};
+
+struct OscState {
+    double oscPos;              // wavetable position (TRMWavetable.m:165-168)
+};
+
+struct FirState {
+    float fir[24];              // transposed-form partial sums of the 49-tap FIR
+};
+
+// `j` = position in the control period (uniform), `sineTab` = 512-entry sine table lookup.
 template <class SineLookup>
-TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, const float *fir, int j, float lpNoise,
-                                SineLookup sineTab)
+TRM_HD OscOut osc_sample(OscState &S, ExciteTrack &T, const Const &C, int j, SineLookup sineTab)
 {
     // amplitude of voicing with its clamps (:294-296), in fp64: it feeds rint() below
     double axd = T.glotDb >= 60.0 ? 1.0 : T.axGeo;
     axd = T.glotDb <= 0.0 ? 0.0 : axd;
-    const float ax = (float)axd;
-    const float ah1 = amplitude_f(fma_f((float)j, T.aspDelta, T.aspBase));
+    OscOut O;
+    O.ax = (float)axd;
+    O.ah1 = amplitude_f(fma_f((float)j, T.aspDelta, T.aspBase));
 
     // glottal source: 2x oversampled wavetable oscillator (TRMWavetable.m:117-195)
-    float wa, wb;   // the two oversampled table reads of this sample
-    {
-        double inc = (T.f0 * 0.5) * C.basicIncrement;
-        double pos1 = S.oscPos + inc;
-        pos1 = pos1 > 511.0 ? pos1 - 512.0 : pos1;          // mod0(), :28-34
-        double pos2 = pos1 + inc;
-        pos2 = pos2 > 511.0 ? pos2 - 512.0 : pos2;
-        S.oscPos = pos2;
-        int lo1 = (int)pos1, lo2 = (int)pos2;
-        float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
-        int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
-        int up2 = lo2 + 1 > 511 ? lo2 + 1 - 512 : lo2 + 1;
-        float a0, a1, b0, b1;
-        if (C.waveform == 0) {
-            int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
-            float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
-            a0 = pulse_table(lo1, C, newDiv2, invFall);
-            a1 = pulse_table(up1, C, newDiv2, invFall);
-            b0 = pulse_table(lo2, C, newDiv2, invFall);
-            b1 = pulse_table(up2, C, newDiv2, invFall);
-        } else {
-            a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
-        }
-        wa = fma_f(fr1, a1 - a0, a0);
-        wb = fma_f(fr2, b1 - b0, b0);
+    double inc = (T.f0 * 0.5) * C.basicIncrement;
+    double pos1 = S.oscPos + inc;
+    pos1 = pos1 > 511.0 ? pos1 - 512.0 : pos1;          // mod0(), :28-34
+    double pos2 = pos1 + inc;
+    pos2 = pos2 > 511.0 ? pos2 - 512.0 : pos2;
+    S.oscPos = pos2;
+    int lo1 = (int)pos1, lo2 = (int)pos2;
+    float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
+    int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
+    int up2 = lo2 + 1 > 511 ? lo2 + 1 - 512 : lo2 + 1;
+    float a0, a1, b0, b1;
+    if (C.waveform == 0) {
+        int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
+        float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
+        a0 = pulse_table(lo1, C, newDiv2, invFall);
+        a1 = pulse_table(up1, C, newDiv2, invFall);
+        b0 = pulse_table(lo2, C, newDiv2, invFall);
+        b1 = pulse_table(up2, C, newDiv2, invFall);
+    } else {
+        a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
     }
+    O.wa = fma_f(fr1, a1 - a0, a0);
+    O.wb = fma_f(fr2, b1 - b0, b0);
+    // advance the fp64 tracks (:351)
+    T.glotDb += T.glotDbDelta;
+    T.axGeo *= T.axRatio;
+    T.f0 *= T.f0Ratio;
+    return O;
+}
+
+// `fir` = the 25 distinct taps (the caller decides where they live), `lpNoise` = the voice-independent
+// low-passed noise sample (uniform).
+TRM_HD Excitation mix_sample(FirState &S, const Const &C, const float *fir, const OscOut &O, float lpNoise)
+{
     // 49-tap FIR, decimate by 2, transposed form: y[m] = sum c[2k] b[m-k] + c[2k+1] a[m-k]
     // (TRMFIRFilter.m:116-146); the partial sums shift for free through the FMA destination.
-    float pulse;
-    {
-        auto c = [&](int i) { return fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };   // fir = the 25 distinct taps
-        pulse = fma_f(c(0), wb, fma_f(c(1), wa, S.fir[0]));
-        for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), wb, fma_f(c(2 * q + 3), wa, S.fir[q + 1]));
-        S.fir[23] = c(48) * wb;
-    }
+    auto c = [&](int i) { return fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };
+    float pulse = fma_f(c(0), O.wb, fma_f(c(1), O.wa, S.fir[0]));
+    for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), O.wb, fma_f(c(2 * q + 3), O.wa, S.fir[q + 1]));
+    S.fir[23] = c(48) * O.wb;
     // source mixing (:315-333)
+    const float ax = O.ax;
     float pulsedNoise = lpNoise * pulse;
     pulse = ax * fma_f(pulsedNoise, C.breath, pulse * (1.0f - C.breath));
     float sig;
@@ -252,13 +273,24 @@ TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, 
     } else
         sig = lpNoise;
     Excitation E;
-    E.gin = fma_f(ah1, sig, pulse) * kVtScale;
+    E.gin = fma_f(O.ah1, sig, pulse) * kVtScale;
     E.sig = sig;
     E.thr = pulse * kVtScale;
-    // advance the fp64 tracks (:351)
-    T.glotDb += T.glotDbDelta;
-    T.axGeo *= T.axRatio;
-    T.f0 *= T.f0Ratio;
+    return E;
+}
+
+// Both halves in one call (host emulation).
+template <class SineLookup>
+TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, const float *fir, int j, float lpNoise,
+                                SineLookup sineTab)
+{
+    OscState os; os.oscPos = S.oscPos;
+    FirState fs;
+    for (int i = 0; i < 24; i++) fs.fir[i] = S.fir[i];
+    OscOut O = osc_sample(os, T, C, j, sineTab);
+    Excitation E = mix_sample(fs, C, fir, O, lpNoise);
+    S.oscPos = os.oscPos;
+    for (int i = 0; i < 24; i++) S.fir[i] = fs.fir[i];
     return E;
 }
 

@@ -28,16 +28,16 @@ for _ in range(2):
 torch.cuda.synchronize()
 L = g.lib()
 nwg = (V + 63) // 64
-NR = 6
+NR = 7
 buf = np.zeros(nwg * NR * 8, dtype=np.uint64)
 L.trm_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.trm_debug_stamps(buf.ctypes.data, buf.size) == 0
 s = buf.reshape(nwg, NR, 8).astype(np.float64)
 ntube = (nframes - 1) * b.derived["controlPeriod"] + 26
-names = ["excite", "coef0", "coef1", "tube", "convert0", "convert1"]
+names = ["osc", "mix", "coef0", "coef1", "tube", "convert0", "convert1"]
 print("voices %d, %d tube samples; cycles per tube sample (median over %d workgroups)" % (V, ntube, nwg))
 for r in range(NR):
     w, q = np.median(s[:, r, 0]) / ntube, np.median(s[:, r, 1]) / ntube
     print("  %-8s work %7.0f  barrier-wait %7.0f  total %7.0f" % (names[r], w, q, w + q))
-sub = np.median(s[:, 4, 2:], axis=0) / ntube
+sub = np.median(s[:, 5, 2:], axis=0) / ntube
 print("  convert0 sub-phases (cycles per tube sample): reads-issue %.0f, readlanes %.0f, dot %.0f, stores %.0f, tile+block-end %.0f" % tuple(sub[:5]))
