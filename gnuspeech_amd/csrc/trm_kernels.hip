@@ -25,6 +25,7 @@ namespace trm {
 constexpr int kWave = 64;
 constexpr int kRoles = 7;            // waves per workgroup: osc, mix, coef x2, tube, convert x2
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
+constexpr int kKQuads = 5;           // coef -> tube: 20 floats per lane per sample
 constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
 constexpr int kNoiseHalf = 64;
 // tube -> convert hand-off: per voice a ring of the last 128 tube-rate samples (+ mirror)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
 {
     __shared__ __attribute__((aligned(16))) float4 sW[2 * kTB * kWave];          // osc -> mix: {wa, wb, ax, ah1}
     __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // mix -> tube: excitation per sample
-    __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * 6 * kWave];      // coefficients per sample
+    __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * kKQuads * kWave]; // coefficients per sample
     __shared__ __attribute__((aligned(16))) float sY[kWave * kYStride];          // tube-rate rings
     __shared__ uint4 sInfo[kWave];                                               // convert: {length, ptr lo, ptr hi} per voice
     __shared__ float sMx[2 * 16 * kWave];                                        // convert: running max |y| per (row, lane)
@@ -275,13 +276,13 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 }
                 Coefs K = coef_sample(T, C, (int)j);
                 j += kTB;
-                float4 *dst = &sK[((buf * kTB + u) * 6) * kWave + lane];
+                // 20 floats per sample: C8, alphaLR and bpAlpha are re-derived by the tube wave (1 op each)
+                float4 *dst = &sK[((buf * kTB + u) * kKQuads) * kWave + lane];
                 dst[0 * kWave] = make_float4(K.k[0], K.k[1], K.k[2], K.k[3]);
-                dst[1 * kWave] = make_float4(K.k[4], K.k[5], K.k[6], K.k[7]);
-                dst[2 * kWave] = make_float4(K.onePlusK8, K.alphaLR, K.alphaU, K.nk1);
+                dst[1 * kWave] = make_float4(K.k[4], K.k[5], K.k[6], K.onePlusK8);
+                dst[2 * kWave] = make_float4(K.alphaU, K.nk1, K.bpBeta, K.bpGamma);
                 dst[3 * kWave] = make_float4(K.tap[0], K.tap[1], K.tap[2], K.tap[3]);
                 dst[4 * kWave] = make_float4(K.tap[4], K.tap[5], K.tap[6], K.tap[7]);
-                dst[5 * kWave] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
             }
             STAMP_MID
             __syncthreads();
@@ -301,18 +302,21 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
         auto one = [&](const Waves &o, Waves &nw, int buf, int u, uint32_t n) {
             const float4 x = sX[(buf * kTB + u) * kWave + lane];
-            const float4 *src = &sK[((buf * kTB + u) * 6) * kWave + lane];
+            const float4 *src = &sK[((buf * kTB + u) * kKQuads) * kWave + lane];
             const float4 k0 = src[0 * kWave], k1 = src[1 * kWave], k2 = src[2 * kWave];
-            const float4 t0 = src[3 * kWave], t1 = src[4 * kWave], bp = src[5 * kWave];
+            const float4 t0 = src[3 * kWave], t1 = src[4 * kWave];
             Excitation E;
             E.gin = x.x; E.sig = x.y; E.thr = x.z;
             Coefs K;
             K.k[0] = k0.x; K.k[1] = k0.y; K.k[2] = k0.z; K.k[3] = k0.w;
-            K.k[4] = k1.x; K.k[5] = k1.y; K.k[6] = k1.z; K.k[7] = k1.w;
-            K.onePlusK8 = k2.x; K.alphaLR = k2.y; K.alphaU = k2.z; K.nk1 = k2.w;
+            K.k[4] = k1.x; K.k[5] = k1.y; K.k[6] = k1.z; K.onePlusK8 = k1.w;
+            K.k[7] = K.onePlusK8 - 1.0f;                 // C8 (near -1 when the mouth closes: no cancellation here)
+            K.alphaU = k2.x; K.nk1 = k2.y; K.bpBeta = k2.z; K.bpGamma = k2.w;
+            K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);    // the three alphas sum to 2 (TRMTubeModel.m:733-736)
+            K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;        // TRMFilters.m:16
             K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
             K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
-            K.bpAlpha = bp.x; K.bpBeta = bp.y; K.bpGamma = bp.z; K.pad_ = 0.0f;
+            K.pad_ = 0.0f;
             float y = tube_step(o, nw, F, C, E, K);
             y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
             // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
