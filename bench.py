@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--workload", default="static", choices=["static", "timevarying"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "quad"],
+                    help="kernel form (include/trm_c_api.h); auto = the library's choice by batch size")
     a = ap.parse_args()
 
     import numpy as np
@@ -80,12 +82,13 @@ def main():
     # per-rank shard: independent voices, different seed offset per rank (no data-path collective)
     if a.workload == "static":
         frames = cases.config2_frames(a.voices, nframes=nframes, seed=20250117 + rank)
-        wname = "configs[1]: batch=%d static-vowel tubes x %.3g s @ 44.1 kHz, Monet default voice, fp32, one tube per lane" % (a.voices, a.seconds)
+        wname = "configs[1]: batch=%d static-vowel tubes x %.3g s @ 44.1 kHz, Monet default voice, fp32" % (a.voices, a.seconds)
     else:
         frames = cases.config3_frames(a.voices, nframes=nframes, seed=20250118 + rank)
         wname = "configs[2]: batch=%d time-varying tubes (gnuspeech.input tracks) x %.3g s @ 44.1 kHz" % (a.voices, a.seconds)
 
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd), device=local_rank)
+    b.set_kernel(a.kernel)
     st = b.prepare_device(frames, device="cuda:%d" % local_rank)
     stream = torch.cuda.current_stream()
 
@@ -136,10 +139,11 @@ def main():
         "realtime_voices_44k1": value / 44100.0,
         "config": {"workload": wname, "voices_per_gpu": a.voices, "frames_per_voice": nframes,
                    "output_samples_per_voice": samples_per_step_rank // max(1, a.voices),
-                   "tube_rate_hz": b.derived["sampleRate"], "control_rate_hz": 250, "sharding": "voices, no collective"},
+                   "tube_rate_hz": b.derived["sampleRate"], "control_rate_hz": 250, "sharding": "voices, no collective",
+                   "kernel_form": b.last_kernel},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "trm_tube_kernel", "avg_launch_ms": kern_ms / max(1, launches),
+                     "kernel": {"wide": "trm_tube_kernel", "quad": "trm_tube_kernel_q"}[b.last_kernel], "avg_launch_ms": kern_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "VALU-issue bound scalar recurrence (SURVEY 8d); HBM-write fraction reported as BASELINE asks"},
     }

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TRM_LIB") or os.path.join(_HERE, "libtrm_hip.so")
 
 TRM_OK = 0
+TRM_KERNEL_AUTO, TRM_KERNEL_WIDE, TRM_KERNEL_QUAD = 0, 1, 2
 (TRM_EINVAL, TRM_EINVAL_LENGTH, TRM_EFIR, TRM_ENOMEM, TRM_EHIP, TRM_ENODEVICE, TRM_EIO, TRM_EPARSE,
  TRM_ESILENT, TRM_ERANGE) = range(1, 11)
 
@@ -52,6 +53,7 @@ EXPORTS = [
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
+    "trm_batch_set_kernel", "trm_batch_last_kernel",
     "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu",
 ]
 
@@ -113,6 +115,8 @@ def lib():
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]
     L.trm_batch_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.trm_batch_set_kernel.argtypes = [vp, C.c_int]
+    L.trm_batch_last_kernel.argtypes = [vp]
     L.trm_batch_noise_table.argtypes = [vp, vp, C.c_size_t]
     for name in EXPORTS:
         getattr(L, name)

@@ -118,6 +118,14 @@ class TRMBatch:
         check(lib().trm_batch_noise_table(self._h, out.ctypes.data, int(n)))
         return out
 
+    def set_kernel(self, kernel):
+        """'auto' | 'wide' (one voice per lane) | 'quad' (four lanes per voice); see include/trm_c_api.h."""
+        check(lib().trm_batch_set_kernel(self._h, {"auto": 0, "wide": 1, "quad": 2}[kernel]))
+
+    @property
+    def last_kernel(self):
+        return {0: "auto", 1: "wide", 2: "quad"}[lib().trm_batch_last_kernel(self._h)]
+
     def kernel_time_ms(self):
         t = C.c_double()
         n = C.c_uint32()

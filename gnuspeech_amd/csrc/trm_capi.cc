@@ -83,6 +83,9 @@ struct trm_batch {
     // kernel timing (hipEvents on the launch stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     bool timing = true;
+    int kernel = TRM_KERNEL_AUTO;        // trm_batch_set_kernel
+    uint32_t wideThreshold = 32768;      // voices from which the one-voice-per-lane kernel fills the chip twice over
+    int lastKernel = TRM_KERNEL_AUTO;    // what the last launch ran
 };
 
 struct trm_tube {
@@ -317,7 +320,19 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    HIP_TRY(trm::launch_tube(b->c, a, stream));
+    // Kernel form: one voice per lane (64 voices per workgroup) once that alone puts two workgroups on
+    // every CU; below that, four lanes per voice (16 voices per workgroup), which advances four tube
+    // samples per pass of the instruction streams and spreads a small batch over four times the CUs.
+    int which = b->kernel;
+    if (which == TRM_KERNEL_AUTO) {
+        if (const char *e = getenv("TRM_TUBE_KERNEL")) which = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : which;
+    }
+    if (which == TRM_KERNEL_AUTO) which = nvoices >= (size_t)b->wideThreshold ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD;
+    b->lastKernel = which;
+    if (which == TRM_KERNEL_QUAD)
+        HIP_TRY(trm::launch_tube_quad(b->c, a, stream));
+    else
+        HIP_TRY(trm::launch_tube(b->c, a, stream));
     if (!b->c.upsample) {
         trm::DownArgs d;
         d.tube = b->dTube.p;
@@ -337,6 +352,16 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     }
     return TRM_OK;
 }
+
+int trm_batch_set_kernel(trm_batch *b, int kernel)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (kernel != TRM_KERNEL_AUTO && kernel != TRM_KERNEL_WIDE && kernel != TRM_KERNEL_QUAD) return fail(TRM_EINVAL, "unknown kernel form %d", kernel);
+    b->kernel = kernel;
+    return TRM_OK;
+}
+
+int trm_batch_last_kernel(const trm_batch *b) { return b ? b->lastKernel : TRM_KERNEL_AUTO; }
 
 int trm_batch_kernel_time_ms(trm_batch *b, double *total_ms, uint32_t *launches)
 {

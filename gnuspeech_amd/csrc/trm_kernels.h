@@ -49,6 +49,9 @@ struct ScaleArgs {
 int tube_kernel_blocks_per_cu();
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
+// small-batch form (trm_quad.hip): 16 voices per workgroup, four lanes per voice
+hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream);
+int tube_quad_kernel_blocks_per_cu();
 // Down-sampling converter (TRMSampleRateConverter.m:234-297) over tube-rate samples in HBM.
 struct DownArgs {
     const float *tube;            // tube-rate samples incl. 2*pad zeros of flush per voice

@@ -13,6 +13,7 @@
 
 #include <type_traits>
 
+#include "trm_devutil.h"
 #include "trm_kernels.h"
 #include "trm_lane.h"
 
@@ -22,17 +23,9 @@
 
 namespace trm {
 
-constexpr int kWave = 64;
 constexpr int kRoles = 7;            // waves per workgroup: osc, mix, coef x2, tube, convert x2
 constexpr int kTB = 2;               // tube samples per pipeline step (one barrier per step)
 constexpr int kKQuads = 5;           // coef -> tube: 20 floats per lane per sample
-constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64
-constexpr int kNoiseHalf = 64;
-// tube -> convert hand-off: per voice a ring of the last 128 tube-rate samples (+ mirror)
-constexpr int kYRing = 128;
-constexpr int kYMirror = 32;          // slots 0..31 repeated after the ring: a 32-sample aligned window never wraps
-constexpr int kYStride = kYRing + kYMirror + 4;   // multiple of 4 floats: 16-byte aligned rows for ds_read_b128
-constexpr int kCvtCols = 32;         // convert: outputs per block (lanes 0-31 / 32-63 = two voices)
 
 __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *state)
 {
@@ -51,70 +44,6 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
     }
     state[0] = seed;
     state[1] = x1;
-}
-
-// ---------------------------------------------------------------- LDS-DMA helpers
-// global_load_lds_*: asynchronous global -> LDS copy, no VGPR destination.  The LDS address is a
-// wave-uniform base (M0) + lane * size; the global source address is per lane.  Completion is
-// tracked by vmcnt; the compiler does not know these writes, so readers wait explicitly.
-typedef __attribute__((address_space(1))) const void *GlobalPtr;
-typedef __attribute__((address_space(3))) void *LdsPtr;
-typedef float v2f __attribute__((ext_vector_type(2)));   // two-wide fp32: v_pk_fma_f32 / v_pk_mul_f32
-
-__device__ __forceinline__ void dma16(const float *src, float *ldsBaseUniform)
-{
-    __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)ldsBaseUniform, 16, 0, 0);
-}
-__device__ __forceinline__ void dma4(const float *src, float *ldsBaseUniform)
-{
-    __builtin_amdgcn_global_load_lds((GlobalPtr)src, (LdsPtr)ldsBaseUniform, 4, 0, 0);
-}
-__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) {
-        uint32_t o = __shfl_xor(v, off, kWave);
-        v = o > v ? o : v;
-    }
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
-// Diagnostic build only (-DTRM_STAMP, tools/stage_profile.py): per-role cycles spent working vs
-// waiting at the step barrier.  In the product build these macros expand to nothing.
-#ifdef TRM_STAMP
-#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0;
-#define SUB_DECL unsigned long long sub_t = 0, sub_acc[6] = {0, 0, 0, 0, 0, 0};
-#define SUB_START sub_t = __builtin_readcyclecounter();
-#define SUB_LAP(i_) { unsigned long long n_ = __builtin_readcyclecounter(); sub_acc[i_] += n_ - sub_t; sub_t = n_; }
-#define SUB_STORE(role_) if (lane == 0 && A.stamps) for (int i_ = 0; i_ < 6; i_++) A.stamps[(blockIdx.x * kRoles + (role_)) * 8 + 2 + i_] = sub_acc[i_];
-#define STAMP_BEGIN st_t0 = __builtin_readcyclecounter();
-#define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0;
-#define STAMP_END st_wait += __builtin_readcyclecounter() - st_t1;
-#define STAMP_STORE(role_)                                                          \
-    if (lane == 0 && A.stamps) {                                                    \
-        A.stamps[(blockIdx.x * kRoles + (role_)) * 8] = st_work;                    \
-        A.stamps[(blockIdx.x * kRoles + (role_)) * 8 + 1] = st_wait;                \
-    }
-#else
-#define STAMP_DECL
-#define SUB_DECL
-#define SUB_START
-#define SUB_LAP(i_)
-#define SUB_STORE(role_)
-#define STAMP_BEGIN
-#define STAMP_MID
-#define STAMP_END
-#define STAMP_STORE(role_)
-#endif
-
-__device__ __forceinline__ void load_frame(const float *frames, uint32_t fi, float *dst, int quads)
-{
-    const float4 *p = reinterpret_cast<const float4 *>(frames + (size_t)fi * 16);
-    for (int q = 0; q < quads; q++) {
-        float4 x = p[q];
-        dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w;
-    }
 }
 
 // One workgroup = 64 voices x 6 waves.
@@ -139,6 +68,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     __shared__ float sMx[2 * 16 * kWave];                                        // convert: running max |y| per (row, lane)
     __shared__ float sNoise[kNoiseRing];                                         // excite: noise ring
 
+    constexpr int kStampRoles = kRoles;
+    (void)kStampRoles;
     const int lane = threadIdx.x & (kWave - 1);
     // wave -> role.  A workgroup's waves are dealt to the CU's 4 SIMDs in turn, so waves w and w+4 share
     // one SIMD's issue slots: TRM_ROLE_PERM lists the role of each wave (diagnostic builds may override it).

@@ -209,6 +209,30 @@ struct FirState {
     float fir[24];              // transposed-form partial sums of the 49-tap FIR
 };
 
+// The two oversampled wavetable reads at positions pos1, pos2 for the amplitude of voicing axd
+// (TRMWavetable.m:117-195): the table is evaluated, not stored.
+template <class SineLookup>
+TRM_HD void osc_read(const Const &C, double axd, double pos1, double pos2, SineLookup sineTab, float &wa, float &wb)
+{
+    int lo1 = (int)pos1, lo2 = (int)pos2;
+    float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
+    int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
+    int up2 = lo2 + 1 > 511 ? lo2 + 1 - 512 : lo2 + 1;
+    float a0, a1, b0, b1;
+    if (C.waveform == 0) {
+        int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
+        float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
+        a0 = pulse_table(lo1, C, newDiv2, invFall);
+        a1 = pulse_table(up1, C, newDiv2, invFall);
+        b0 = pulse_table(lo2, C, newDiv2, invFall);
+        b1 = pulse_table(up2, C, newDiv2, invFall);
+    } else {
+        a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
+    }
+    wa = fma_f(fr1, a1 - a0, a0);
+    wb = fma_f(fr2, b1 - b0, b0);
+}
+
 // `j` = position in the control period (uniform), `sineTab` = 512-entry sine table lookup.
 template <class SineLookup>
 TRM_HD OscOut osc_sample(OscState &S, ExciteTrack &T, const Const &C, int j, SineLookup sineTab)
@@ -227,28 +251,31 @@ TRM_HD OscOut osc_sample(OscState &S, ExciteTrack &T, const Const &C, int j, Sin
     double pos2 = pos1 + inc;
     pos2 = pos2 > 511.0 ? pos2 - 512.0 : pos2;
     S.oscPos = pos2;
-    int lo1 = (int)pos1, lo2 = (int)pos2;
-    float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
-    int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
-    int up2 = lo2 + 1 > 511 ? lo2 + 1 - 512 : lo2 + 1;
-    float a0, a1, b0, b1;
-    if (C.waveform == 0) {
-        int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
-        float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
-        a0 = pulse_table(lo1, C, newDiv2, invFall);
-        a1 = pulse_table(up1, C, newDiv2, invFall);
-        b0 = pulse_table(lo2, C, newDiv2, invFall);
-        b1 = pulse_table(up2, C, newDiv2, invFall);
-    } else {
-        a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
-    }
-    O.wa = fma_f(fr1, a1 - a0, a0);
-    O.wb = fma_f(fr2, b1 - b0, b0);
+    osc_read(C, axd, pos1, pos2, sineTab, O.wa, O.wb);
     // advance the fp64 tracks (:351)
     T.glotDb += T.glotDbDelta;
     T.axGeo *= T.axRatio;
     T.f0 *= T.f0Ratio;
     return O;
+}
+
+// source mixing (TRMTubeModel.m:315-341) from the FIR output `pulse`
+TRM_HD Excitation mix_tail(const Const &C, float ax, float ah1, float pulse, float lpNoise)
+{
+    float pulsedNoise = lpNoise * pulse;
+    pulse = ax * fma_f(pulsedNoise, C.breath, pulse * (1.0f - C.breath));
+    float sig;
+    if (C.usesModulation) {
+        float cm = ax * C.crossmixFactor;
+        cm = cm < 1.0f ? cm : 1.0f;
+        sig = fma_f(pulsedNoise, cm, lpNoise * (1.0f - cm));
+    } else
+        sig = lpNoise;
+    Excitation E;
+    E.gin = fma_f(ah1, sig, pulse) * kVtScale;
+    E.sig = sig;
+    E.thr = pulse * kVtScale;
+    return E;
 }
 
 // `fir` = the 25 distinct taps (the caller decides where they live), `lpNoise` = the voice-independent
@@ -261,22 +288,7 @@ TRM_HD Excitation mix_sample(FirState &S, const Const &C, const float *fir, cons
     float pulse = fma_f(c(0), O.wb, fma_f(c(1), O.wa, S.fir[0]));
     for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), O.wb, fma_f(c(2 * q + 3), O.wa, S.fir[q + 1]));
     S.fir[23] = c(48) * O.wb;
-    // source mixing (:315-333)
-    const float ax = O.ax;
-    float pulsedNoise = lpNoise * pulse;
-    pulse = ax * fma_f(pulsedNoise, C.breath, pulse * (1.0f - C.breath));
-    float sig;
-    if (C.usesModulation) {
-        float cm = ax * C.crossmixFactor;
-        cm = cm < 1.0f ? cm : 1.0f;
-        sig = fma_f(pulsedNoise, cm, lpNoise * (1.0f - cm));
-    } else
-        sig = lpNoise;
-    Excitation E;
-    E.gin = fma_f(O.ah1, sig, pulse) * kVtScale;
-    E.sig = sig;
-    E.thr = pulse * kVtScale;
-    return E;
+    return mix_tail(C, O.ax, O.ah1, pulse, lpNoise);
 }
 
 // Both halves in one call (host emulation).

@@ -1,0 +1,393 @@
+// trm_quad.hip -- trm_tube_kernel_q: -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361) for batches too
+// small to fill the chip with one voice per lane.
+//
+// A batch of V voices has V serial recurrences of ~20 k tube samples per second of speech; with one voice
+// per lane (trm_kernels.hip) 4096 voices are 64 workgroups on 64 of 256 CUs and every sample costs a full
+// pass of five instruction streams.  Here a workgroup carries 16 voices and every voice owns FOUR lanes:
+//   osc, mix, coef   lanes = 4 consecutive tube samples of a voice (the stages are feed-forward in time; the
+//                    oscillator phase is a 4-wide prefix sum, the FIR runs in direct form over an LDS ring)
+//   tube             lanes = 4 parts of the tube, junction values crossing a part boundary move by DPP
+//   convert          lane = output time, as in the wide kernel (rows of 32 outputs x 2 voices)
+// so one pass of the instruction streams advances 4 tube samples and 256 workgroups cover 4096 voices.
+// One barrier per step of kQB = 4 tube samples; osc works on block i, mix and coef on block i-1, tube on
+// block i-2, convert on whatever is complete, metered.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "trm_devutil.h"
+#include "trm_kernels.h"
+#include "trm_lane.h"
+#include "trm_quad.h"
+
+namespace trm {
+
+constexpr int kQV = 16;              // voices per workgroup
+constexpr int kQB = kSlots;          // tube samples per step = time slots per voice
+constexpr int kQRoles = 5;           // osc, mix, coef, tube, convert
+constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
+constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
+constexpr int kOStride = kORing + kOMirror;
+constexpr int kKRec = 8;             // coef -> tube: float4s per (sample, voice): 4 parts x {kk, tp}
+
+__global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const C, const TubeArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float2 sO[kQV * kOStride];            // osc -> mix: oscillator reads
+    __shared__ __attribute__((aligned(16))) float2 sA[2 * kWave];                 // osc -> mix: {ax, ah1}
+    __shared__ __attribute__((aligned(16))) float4 sX[2 * kWave];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
+    __shared__ __attribute__((aligned(16))) float4 sBP[2 * kWave];                // coef -> tube: band-pass
+    __shared__ __attribute__((aligned(16))) float4 sK[2 * kQB * kKRec * kQV];     // coef -> tube: part records
+    __shared__ __attribute__((aligned(16))) float sY[kQV * kYStride];             // tube-rate rings
+    __shared__ uint4 sInfo[kQV];
+    __shared__ float sMx[8 * kWave];
+    __shared__ float sNoise[kNoiseRing];
+
+    constexpr int kStampRoles = kQRoles;
+    (void)kStampRoles;
+    const int lane = threadIdx.x & (kWave - 1);
+    // wave -> role: waves w and w+4 share a SIMD; the tube wave (the only serial one) gets a SIMD to itself
+    const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifndef TRM_QROLE_PERM
+#define TRM_QROLE_PERM 4, 2, 1, 3, 0      /* convert coef mix tube | osc */
+#endif
+    const int rolePerm[kQRoles] = {TRM_QROLE_PERM};
+    int role = 0;
+    for (int i = 0; i < kQRoles; i++) role = waveIdx == i ? rolePerm[i] : role;
+
+    // lane -> (voice, slot/part): a row of 16 lanes = 4 banks (slot/part) x 4 voices
+    const int part = (lane >> 2) & 3;
+    const int vq = (lane >> 4) * 4 + (lane & 3);        // voice within the workgroup
+    const uint32_t vRaw = blockIdx.x * kQV + vq;
+    const bool laneValid = vRaw < A.nvoices;
+    const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
+
+    const uint32_t nfr = A.nframes[v];
+    const uint32_t nfrMax = wave_max_u32(nfr);
+    const uint32_t CP = (uint32_t)C.controlPeriod;
+    const uint32_t inc = C.timeRegisterIncrement;
+    const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
+    const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
+    // the tube stage steps block i-2 at step i; the convert wave finishes what is queued after the last barrier
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 3 : 0;
+    const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
+    const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
+    auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
+
+    for (int i = threadIdx.x; i < kQV * kYStride; i += kWave * kQRoles) sY[i] = 0.0f;
+    for (int i = threadIdx.x; i < kQV * kOStride; i += kWave * kQRoles) sO[i] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+
+    if (role == 0) {
+        // ------------------------------------------------------------ osc: block i at step i, lane = (voice, slot)
+        auto sine = [&](int i) { return sine_table(i); };
+        OscSlotTrack T;
+        double P = 0.0;                                 // oscillator position at the start of the block
+        float prev[4], cur[4], nxt[4];
+        uint32_t per = 0, j = (uint32_t)part;           // control period / position in it of this lane's sample
+        if (nSteps > 0) {
+            load_frame(frames, frame_index(0), prev, 1);
+            load_frame(frames, frame_index(1), cur, 1);
+            load_frame(frames, frame_index(2), nxt, 1);
+            osc_slot_setup(T, C, prev, cur, (int)j);
+        }
+        float2 *const ring = &sO[vq * kOStride];
+        STAMP_DECL
+        for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
+            if (step * kQB < nTotal) {
+                if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
+                    j -= CP;
+                    per++;
+                    for (int q = 0; q < 4; q++) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+                    load_frame(frames, frame_index(per + 2), nxt, 1);
+                    osc_slot_setup(T, C, prev, cur, (int)j);
+                }
+                const double db = __builtin_fma((double)j, T.glotDelta, T.glot0);
+                double axd = db >= 60.0 ? 1.0 : T.axGeo;      // amplitude() with its clamps (:294-296)
+                axd = db <= 0.0 ? 0.0 : axd;
+                const float ah1 = amplitude_f(fma_f((float)j, T.aspDelta, T.aspBase));
+                const double oinc = (T.f0 * 0.5) * C.basicIncrement;
+                // position after this lane's sample = P + the inclusive prefix sum of 2*inc over the slots
+                double pre = oinc + oinc;
+                pre += q_take<1, kPart1 | kPart2 | kPart3>(0.0, pre);
+                pre += q_take<2, kPart2 | kPart3>(0.0, pre);
+                const double end = P + pre;
+                const double pos2 = osc_wrap(end), pos1 = osc_wrap(end - oinc);
+                double tot = pre;                                // slot 3's prefix = the block's advance
+                tot = q_take<1, kPart0>(tot, pre);
+                tot = q_take<2, kPart1>(tot, pre);
+                tot = q_take<3, kPart2>(tot, pre);
+                P = osc_wrap(P + tot);
+                float wa, wb;
+                osc_read(C, axd, pos1, pos2, sine, wa, wb);
+                T.f0 *= T.f0Step;
+                T.axGeo *= T.axStep;
+                j += kQB;
+                const uint32_t slot = (step * kQB + (uint32_t)part) & (kORing - 1);
+                ring[slot] = make_float2(wa, wb);
+                if (slot < (uint32_t)kOMirror) ring[slot + kORing] = make_float2(wa, wb);
+                sA[(step & 1) * kWave + lane] = make_float2((float)axd, ah1);
+            }
+            STAMP_MID
+            __syncthreads();
+            STAMP_END
+        }
+        STAMP_STORE(role)
+    } else if (role == 1) {
+        // ------------------------------------------------------------ mix: block i-1 at step i, lane = (voice, slot)
+        auto fill_noise_half = [&](uint32_t nFirst, int half) {
+            dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
+        };
+        // window taps of this lane's parity (m & 1 == part & 1: blocks start on multiples of 4)
+        const int o = part & 1;
+        float ca[kFirWin], cb[kFirWin];
+        for (int i = 0; i < kFirWin; i++) {
+            ca[i] = o ? fir_window_tap_a(C.fir, 1, i) : fir_window_tap_a(C.fir, 0, i);
+            cb[i] = o ? fir_window_tap_b(C.fir, 1, i) : fir_window_tap_b(C.fir, 0, i);
+        }
+        if (nSteps > 0) {
+            fill_noise_half(0, 0);
+            fill_noise_half(kNoiseHalf, 1);
+            dma_wait_all();
+        }
+        const float2 *const ring = &sO[vq * kOStride];
+        STAMP_DECL
+        for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
+            if (step >= 1 && (step - 1) * kQB < nTotal) {
+                const uint32_t blk = step - 1;
+                const int buf = blk & 1;
+                const uint32_t n0 = blk * kQB;
+                if ((n0 & (kNoiseHalf - 1)) == 0 && n0 > 0) {
+                    // entering a noise half: it was requested one half ago; refill the other half
+                    dma_wait_all();
+                    fill_noise_half(n0 + kNoiseHalf, ((n0 / kNoiseHalf) + 1) & 1);
+                }
+                const uint32_t m = n0 + (uint32_t)part;
+                // 26-sample window starting at the even index m - 24 - o (zeros before the first sample)
+                const uint32_t s0 = (m + kORing - 24u - (uint32_t)o) & (kORing - 1);
+                const float4 *wp = reinterpret_cast<const float4 *>(&ring[s0]);
+                float win[2 * kFirWin];
+                for (int q = 0; q < kFirWin / 2; q++) {
+                    const float4 x = wp[q];
+                    win[4 * q] = x.x; win[4 * q + 1] = x.y; win[4 * q + 2] = x.z; win[4 * q + 3] = x.w;
+                }
+                const float pulse = fir_direct(win, ca, cb);
+                const float2 a = sA[buf * kWave + lane];
+                const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
+                sX[buf * kWave + part * kQV + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+            }
+            STAMP_MID
+            __syncthreads();
+            STAMP_END
+        }
+        STAMP_STORE(role)
+        dma_wait_all();
+    } else if (role == 2) {
+        // ------------------------------------------------------------ coef: block i-1 at step i, lane = (voice, slot)
+        CoefTrack T;
+        float prev[16], cur[16], nxt[16];
+        uint32_t per = 0, j = (uint32_t)part;
+        if (nSteps > 0) {
+            load_frame(frames, frame_index(0), prev, 4);
+            load_frame(frames, frame_index(1), cur, 4);
+            load_frame(frames, frame_index(2), nxt, 4);
+            coef_track_setup(T, C, prev, cur);
+        }
+        STAMP_DECL
+        for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
+            if (step >= 1 && (step - 1) * kQB < nTotal) {
+                const int buf = (step - 1) & 1;
+                if (j >= CP) {
+                    j -= CP;
+                    per++;
+                    for (int q = 0; q < 16; q++) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+                    load_frame(frames, frame_index(per + 2), nxt, 4);
+                    coef_track_setup(T, C, prev, cur);
+                }
+                const Coefs K = coef_sample(T, C, (int)j);
+                j += kQB;
+                PartRecord R[4];
+                pack_part_records(K, C, R);
+                // [buf][slot][record quad][voice]
+                float4 *dst = &sK[((buf * kQB + part) * kKRec) * kQV + vq];
+                for (int p = 0; p < 4; p++) {
+                    dst[(2 * p) * kQV] = make_float4(R[p].kk[0], R[p].kk[1], R[p].kk[2], R[p].kk[3]);
+                    dst[(2 * p + 1) * kQV] = make_float4(R[p].tp[0], R[p].tp[1], R[p].tp[2], R[p].tp[3]);
+                }
+                sBP[buf * kWave + part * kQV + vq] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
+            }
+            STAMP_MID
+            __syncthreads();
+            STAMP_END
+        }
+        STAMP_STORE(role)
+    } else if (role == 3) {
+        // ------------------------------------------------------------ tube: block i-2 at step i, lane = (voice, part)
+        QuadState<float> S;
+        quad_reset(S);
+        QuadConst<float> Q;
+        {
+            float a[4], b[4], c[4], e[4];
+            quad_const_parts(C, a, b, c, e);
+            Q.endCoeff = part == 0 ? a[0] : a[2];
+            Q.endA10 = part == 0 ? b[0] : b[2];
+            Q.endK = part == 0 ? c[0] : c[2];
+            Q.endOnePlus = part == 0 ? e[0] : e[2];
+        }
+        float *const ring = &sY[vq * kYStride];
+        float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
+        STAMP_DECL
+        for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
+            if (step >= 2 && (step - 2) * kQB < nTotal) {
+                const uint32_t blk = step - 2;
+                const int buf = blk & 1;
+#pragma unroll
+                for (int s = 0; s < kQB; s++) {
+                    // (samples past nTotal in the last block step on stale inputs; their output is forced to 0)
+                    const uint32_t n = blk * kQB + s;
+                    const float4 x = sX[buf * kWave + s * kQV + vq];
+                    const float4 bp = sBP[buf * kWave + s * kQV + vq];
+                    const float4 *rec = &sK[((buf * kQB + s) * kKRec + 2 * part) * kQV + vq];
+                    const float4 k4 = rec[0], t4 = rec[kQV];
+                    const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, tp[4] = {t4.x, t4.y, t4.z, t4.w};
+                    float y = tube_quad_step<float>(S, Q, C, x.x, x.y, x.z, bp.x, bp.y, bp.z, kk, tp);
+                    y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
+                    if (part == 2) {
+                        const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
+                        ring[slot] = y;
+                        if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;
+                        if (tubeOut && laneValid && n < ntubeLane + 2u * (uint32_t)C.padSize) tubeOut[n] = y;
+                    }
+                }
+            }
+            STAMP_MID
+            __syncthreads();
+            STAMP_END
+        }
+        STAMP_STORE(role)
+    } else {
+        // ------------------------------------------------------------ convert (lane = output time), 16 voices
+        uint32_t noutLane = 0;
+        if (nfr > 0) {
+            uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
+            noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
+        }
+        if (!laneValid) noutLane = 0;
+        const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v]);
+        const uint32_t noutMax = wave_max_u32(noutLane);
+        const uint32_t nBlocks = C.upsample ? (noutMax + kCvtCols - 1) / kCvtCols : 0;
+        const int col = lane & (kCvtCols - 1);
+        const bool upper = lane >= kCvtCols;
+        if (part == 0) sInfo[vq] = make_uint4(noutLane, (uint32_t)myOut, (uint32_t)(myOut >> 32), 0u);
+        // running max |y| per (row, lane): row r = voices 2r (lanes 0-31) and 2r+1 (lanes 32-63)
+        for (int r = 0; r < 8; r++) sMx[r * kWave + lane] = 0.0f;
+
+        v2f cc[16];
+        auto fetch_row = [&](uint32_t blk) {
+            const uint32_t k = blk * kCvtCols + col;
+            const uint32_t off = src_position(k, inc) & 3u;
+            const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
+            for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
+        };
+        uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..3) of block `blk`: voices 4*pr .. 4*pr+3
+        uint32_t winBase = 0, kLane = 0, needLast = 0;
+        auto begin_block = [&]() {
+            kLane = blk * kCvtCols + col;
+            winBase = src_position(kLane, inc) & (kYRing - 1) & ~3u;
+            needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
+            needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
+            fetch_row(blk);
+        };
+        if (nBlocks > 0) begin_block();
+        typedef __attribute__((address_space(1))) float *GlobalFloatPtr;
+        typedef __attribute__((address_space(3))) float *LdsFloatPtr;
+        // metering (16.16 row pairs per step): a step's kQB tube samples turn into kQB * 2^16/inc outputs per
+        // voice = that / 32 blocks of 4 row pairs
+        const uint32_t earn = (uint32_t)(((uint64_t)kQB << 32) / inc / 8) + 2048;
+        uint32_t credit = 0;
+        auto do_pair = [&]() {
+            const int la = 4 * (int)pr, lb = la + 2;
+            const int ha = upper ? 1 : 0;
+            const float4 *wa = reinterpret_cast<const float4 *>(&sY[(la + ha) * kYStride + winBase]);
+            const float4 *wb = reinterpret_cast<const float4 *>(&sY[(lb + ha) * kYStride + winBase]);
+            float4 qa[8], qb[8];
+            for (int q = 0; q < 8; q++) { qa[q] = wa[q]; qb[q] = wb[q]; }
+            const uint4 ia = sInfo[la + ha], ib = sInfo[lb + ha];
+            v2f a0 = v2f{qa[0].x, qa[0].y} * cc[0], a1 = v2f{qa[0].z, qa[0].w} * cc[1];
+            v2f b0 = v2f{qb[0].x, qb[0].y} * cc[0], b1 = v2f{qb[0].z, qb[0].w} * cc[1];
+            for (int q = 1; q < 8; q++) {
+                a0 = __builtin_elementwise_fma(v2f{qa[q].x, qa[q].y}, cc[2 * q], a0);
+                a1 = __builtin_elementwise_fma(v2f{qa[q].z, qa[q].w}, cc[2 * q + 1], a1);
+                b0 = __builtin_elementwise_fma(v2f{qb[q].x, qb[q].y}, cc[2 * q], b0);
+                b1 = __builtin_elementwise_fma(v2f{qb[q].z, qb[q].w}, cc[2 * q + 1], b1);
+            }
+            a0 += a1;
+            b0 += b1;
+            const float ya = a0.x + a0.y, yb = b0.x + b0.y;
+            const bool okA = kLane < ia.x, okB = kLane < ib.x;
+            if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ia.z << 32) | ia.y)[kLane] = ya;
+            if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ib.z << 32) | ib.y)[kLane] = yb;
+            __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMx[(2 * pr) * kWave + lane], okA ? fabsf(ya) : 0.0f, 0, 0, false);
+            __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMx[(2 * pr + 1) * kWave + lane], okB ? fabsf(yb) : 0.0f, 0, 0, false);
+            if (++pr == 4) {
+                pr = 0;
+                blk++;
+                if (blk < nBlocks) begin_block();
+            }
+        };
+        STAMP_DECL
+        for (uint32_t step = 0; step < nSteps; step++) {
+            STAMP_BEGIN
+            // visible after the previous barrier: tube samples n < (step-2)*kQB
+            const uint32_t ready = step >= 2 ? (step - 2) * kQB : 0;
+            credit += earn;
+            if (credit > (4u << 16)) credit = 4u << 16;
+            while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {
+                credit -= 1u << 16;
+                do_pair();
+            }
+            STAMP_MID
+            __syncthreads();
+            STAMP_END
+        }
+        STAMP_STORE(role)
+        while (blk < nBlocks) do_pair();
+        float myMax = 0.0f;     // collected by lanes 0..15: voice `lane` of the workgroup
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            float m = sMx[r * kWave + lane];
+            for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+            const float lowHalf = __shfl(m, 0, kWave), highHalf = __shfl(m, 32, kWave);
+            if (lane == 2 * r) myMax = lowHalf;
+            if (lane == 2 * r + 1) myMax = highHalf;
+        }
+        const uint32_t ov = blockIdx.x * kQV + (uint32_t)lane;
+        if (lane < kQV && ov < A.nvoices && C.upsample) {
+            const uint32_t nf = A.nframes[ov];
+            uint32_t nov = 0;
+            if (nf > 0) nov = (uint32_t)((((uint64_t)(nf - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);
+            A.number_samples[ov] = nov;
+            A.max_sample[ov] = myMax;
+        }
+        return;
+    }
+}
+
+hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream)
+{
+    if (a.nvoices == 0) return hipSuccess;
+    uint32_t grid = (a.nvoices + kQV - 1) / kQV;
+    hipLaunchKernelGGL(trm_tube_kernel_q, dim3(grid), dim3(kWave * kQRoles), 0, stream, c, a);
+    return hipGetLastError();
+}
+
+int tube_quad_kernel_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel_q, kWave * kQRoles, 0) != hipSuccess) return -1;
+    return n;
+}
+
+}  // namespace trm

@@ -188,6 +188,17 @@ int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,
                                      const uint32_t *d_number_samples, const float *d_max_sample,
                                      int16_t *d_int16, int for_wav_data, void *stream);
 
+/* Kernel form of the synthesis launch.  Both forms compute the same samples (same arithmetic per value);
+ * they differ in how a voice is laid out on the machine:
+ *   TRM_KERNEL_WIDE  one voice per lane, 64 voices per workgroup: highest throughput once the batch fills
+ *                    the chip (>= ~32 k voices);
+ *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: lowest latency for smaller batches.
+ * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad
+ * overrides AUTO (diagnostics).  No reference counterpart: the reference runs one tube per thread. */
+enum { TRM_KERNEL_AUTO = 0, TRM_KERNEL_WIDE = 1, TRM_KERNEL_QUAD = 2 };
+int  trm_batch_set_kernel(trm_batch *batch, int kernel);
+int  trm_batch_last_kernel(const trm_batch *batch);
+
 /* Average device time (ms) of the tube kernel launches since the last call, measured
  * with hipEvents on the launch stream; resets the accumulator.  Used by bench.py. */
 int  trm_batch_kernel_time_ms(trm_batch *batch, double *total_ms, uint32_t *launches);

@@ -2,6 +2,7 @@
 // stage arithmetic the HIP kernel executes) serially on the host, one voice at a time, so the
 // fp32/fp64 precision plan can be checked against the oracle in a container without a GPU.  Never
 // linked into libtrm_hip.so and never used by the product path.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -67,4 +68,186 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
     *nout = (uint32_t)total;
     *maxv = mx;
     return TRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The small-batch formulation (gnuspeech_amd/csrc/trm_quad.h): four time slots per voice in the
+// feed-forward stages (closed-form tracks, oscillator phase as a prefix sum, direct-form FIR) and the
+// tube split over four parts.  Same interface as above.
+#include "../../gnuspeech_amd/csrc/trm_quad.h"
+
+extern "C" int trm_emul_synthesize_quad(const trm_input_params *p, const float *frames, size_t nframes,
+                                        float *out, size_t cap, uint32_t *nout, float *maxv, float *tube)
+{
+    Const C;
+    trm_derived d;
+    int rc = build_const(*p, C, d);
+    if (rc) return rc;
+    if (!C.upsample || C.controlPeriod < kSlots) return TRM_ERANGE;
+    static std::vector<float> rows;
+    if (rows.empty()) build_src_rows(rows);
+    *nout = 0; *maxv = 0.f;
+    if (nframes == 0) return TRM_OK;
+    const size_t CP = (size_t)C.controlPeriod;
+    size_t ntube = (nframes - 1) * CP;
+    std::vector<float> lp(ntube + 8);
+    {
+        double seed = 0.7892347, x1 = 0.0;
+        for (size_t i = 0; i < ntube + 8; i++) {
+            double prod = seed * 377.0;
+            seed = prod - (int)prod;
+            double nz = seed - 0.5;
+            lp[i] = (float)(nz + x1);
+            x1 = nz;
+        }
+    }
+    auto sineLookup = [&](int i) { return sine_table(i); };
+    auto frame = [&](size_t i) { return frames + 16 * (i < nframes ? i : nframes - 1); };
+    std::vector<float> sig(25 + ntube + 2 * C.padSize + 8, 0.0f);
+    // osc history ring, unrolled: (a, b) per tube sample with 26 zero pairs in front
+    std::vector<float> ab(2 * (26 + ntube + 8), 0.0f);
+    float ca[2][kFirWin], cb[2][kFirWin];
+    for (int o = 0; o < 2; o++)
+        for (int i = 0; i < kFirWin; i++) { ca[o][i] = fir_window_tap_a(C.fir, o, i); cb[o][i] = fir_window_tap_b(C.fir, o, i); }
+
+    OscSlotTrack OT[kSlots];
+    CoefTrack CT[kSlots];
+    size_t per[kSlots];              // control period of each slot's current sample
+    int jj[kSlots];
+    for (int s = 0; s < kSlots; s++) {
+        per[s] = 0; jj[s] = s;
+        osc_slot_setup(OT[s], C, frame(0), frame(1), s);
+        coef_track_setup(CT[s], C, frame(0), frame(1));
+    }
+    double P = 0.0;
+    QuadState<Q4> QS;
+    quad_reset(QS);
+    QuadConst<Q4> QC;
+    {
+        float a[4], b[4], c[4], e[4];
+        quad_const_parts(C, a, b, c, e);
+        QC.endCoeff = Q4(a[0], a[1], a[2], a[3]); QC.endA10 = Q4(b[0], b[1], b[2], b[3]);
+        QC.endK = Q4(c[0], c[1], c[2], c[3]); QC.endOnePlus = Q4(e[0], e[1], e[2], e[3]);
+    }
+    for (size_t n0 = 0; n0 < ntube; n0 += kSlots) {
+        // ---- osc: slots in parallel, phase by prefix sum
+        double two[kSlots], incs[kSlots], axd[kSlots];
+        float ax[kSlots], ah1[kSlots];
+        for (int s = 0; s < kSlots; s++) {
+            if (jj[s] >= (int)CP) {
+                jj[s] -= (int)CP; per[s]++;
+                osc_slot_setup(OT[s], C, frame(per[s]), frame(per[s] + 1), jj[s]);
+                coef_track_setup(CT[s], C, frame(per[s]), frame(per[s] + 1));
+            }
+            double db = __builtin_fma((double)jj[s], OT[s].glotDelta, OT[s].glot0);
+            double a = db >= 60.0 ? 1.0 : OT[s].axGeo;
+            axd[s] = db <= 0.0 ? 0.0 : a;
+            ax[s] = (float)axd[s];
+            ah1[s] = amplitude_f(fma_f((float)jj[s], OT[s].aspDelta, OT[s].aspBase));
+            incs[s] = (OT[s].f0 * 0.5) * C.basicIncrement;
+            two[s] = incs[s] + incs[s];
+        }
+        double pre[kSlots];
+        for (int s = 0; s < kSlots; s++) pre[s] = two[s];
+        for (int s = kSlots - 1; s >= 1; s--) pre[s] += pre[s - 1];                  // x += shift1(x)
+        for (int s = kSlots - 1; s >= 2; s--) pre[s] += pre[s - 2];                  // x += shift2(x)
+        for (int s = 0; s < kSlots; s++) {
+            double pos2 = osc_wrap(P + pre[s]), pos1 = osc_wrap((P + pre[s]) - incs[s]);
+            float wa, wb;
+            osc_read(C, axd[s], pos1, pos2, sineLookup, wa, wb);
+            ab[2 * (26 + n0 + s)] = wa; ab[2 * (26 + n0 + s) + 1] = wb;
+            OT[s].f0 *= OT[s].f0Step;
+            OT[s].axGeo *= OT[s].axStep;
+        }
+        P = osc_wrap(P + pre[kSlots - 1]);
+        // ---- mix + coef per slot, then the tube serially over the block
+        for (int s = 0; s < kSlots && n0 + s < ntube; s++) {
+            size_t m = n0 + s;
+            int o = (int)(m & 1);
+            const float *win = &ab[2 * (26 + m - 24 - o)];
+            float pulse = fir_direct(win, ca[o], cb[o]);
+            Excitation E = mix_tail(C, ax[s], ah1[s], pulse, lp[m]);
+            Coefs K = coef_sample(CT[s], C, jj[s]);
+            PartRecord R[4];
+            pack_part_records(K, C, R);
+            Q4 kk[4], tp[4];
+            for (int r = 0; r < 4; r++) {
+                kk[r] = Q4(R[0].kk[r], R[1].kk[r], R[2].kk[r], R[3].kk[r]);
+                tp[r] = Q4(R[0].tp[r], R[1].tp[r], R[2].tp[r], R[3].tp[r]);
+            }
+            Q4 y = tube_quad_step(QS, QC, C, Q4(E.gin), Q4(E.sig), Q4(E.thr), Q4(K.bpAlpha), Q4(K.bpBeta), Q4(K.bpGamma), kk, tp);
+            if (tube) tube[m] = y.v[2];
+            sig[25 + m] = y.v[2];
+        }
+        for (int s = 0; s < kSlots; s++) jj[s] += kSlots;
+    }
+    uint64_t total = count_outputs(d, ntube);
+    float mx = 0.f;
+    for (uint64_t k = 0; k < total; k++) {
+        uint32_t ph = src_phase((uint32_t)k, C.timeRegisterIncrement);
+        uint32_t e = src_position((uint32_t)k, C.timeRegisterIncrement);
+        float y = src_dot(&sig[e], &rows[(size_t)ph * kSrcRowC]);
+        if (k < cap) out[k] = y;
+        float a = fabsf(y);
+        if (a > mx) mx = a;
+    }
+    *nout = (uint32_t)total;
+    *maxv = mx;
+    return TRM_OK;
+}
+
+// tube_quad_step against tube_step on random state/coefficients: returns the number of mismatching
+// values over `iters` steps (0 = the four-part data movement is exact).
+extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, unsigned seed)
+{
+    Const C;
+    trm_derived d;
+    if (build_const(*p, C, d)) return -1;
+    srand(seed);
+    auto rnd = [&]() { return (float)rand() / (float)RAND_MAX * 2.0f - 1.0f; };
+    TubeState TS; tube_reset(TS);
+    QuadState<Q4> QS; quad_reset(QS);
+    QuadConst<Q4> QC;
+    float a[4], b[4], c[4], e[4];
+    quad_const_parts(C, a, b, c, e);
+    QC.endCoeff = Q4(a[0], a[1], a[2], a[3]); QC.endA10 = Q4(b[0], b[1], b[2], b[3]);
+    QC.endK = Q4(c[0], c[1], c[2], c[3]); QC.endOnePlus = Q4(e[0], e[1], e[2], e[3]);
+    int bad = 0;
+    for (int it = 0; it < iters; it++) {
+        if (it % 200 == 0) { tube_reset(TS); quad_reset(QS); }   // random coefficients are not a passive tube: keep it finite
+        Coefs K;
+        for (int i = 0; i < 7; i++) K.k[i] = rnd() * 0.9f;
+        K.onePlusK8 = 1.0f + rnd() * 0.9f;
+        K.k[7] = K.onePlusK8 - 1.0f;
+        K.alphaU = rnd() * 0.5f + 0.5f;
+        K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);
+        K.nk1 = rnd() * 0.9f;
+        for (int i = 0; i < 8; i++) K.tap[i] = rnd() * 0.1f;
+        K.bpBeta = 0.2f + rnd() * 0.2f; K.bpGamma = rnd() * 0.3f; K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
+        Excitation E; E.gin = rnd(); E.sig = rnd(); E.thr = rnd();
+        float y0 = tube_sample(TS, C, E, K);
+        PartRecord R[4];
+        pack_part_records(K, C, R);
+        Q4 kk[4], tp[4];
+        for (int r = 0; r < 4; r++) {
+            kk[r] = Q4(R[0].kk[r], R[1].kk[r], R[2].kk[r], R[3].kk[r]);
+            tp[r] = Q4(R[0].tp[r], R[1].tp[r], R[2].tp[r], R[3].tp[r]);
+        }
+        Q4 y = tube_quad_step(QS, QC, C, Q4(E.gin), Q4(E.sig), Q4(E.thr), Q4(K.bpAlpha), Q4(K.bpBeta), Q4(K.bpGamma), kk, tp);
+        if (y.v[2] != y0) { if (bad < 5) fprintf(stderr, "it %d: y %g vs %g\n", it, y.v[2], y0); bad++; }
+        // state correspondence
+        const Waves &w = TS.w;
+        const float exp_[] = {w.oT[0], w.oT[1], w.oB[0], w.oT[2], w.oB[1], w.oT[3], w.oB[2], w.oB[3], w.oT[4], w.nT[0],
+                              w.oT[5], w.oB[4], w.oT[6], w.oB[5], w.oT[7], w.oB[6], w.oT[8], w.oB[7], w.oT[9], w.oB[8],
+                              w.oB[9], w.nT[1], w.nB[0], w.nT[2], w.nB[1], w.nT[3], w.nB[2], w.nT[4], w.nB[3], w.nT[5],
+                              w.nB[4], w.nB[5]};
+        const float got[] = {QS.G.v[0], QS.T[0].v[0], QS.B[0].v[0], QS.T[1].v[0], QS.B[1].v[0], QS.T[2].v[0], QS.B[2].v[0],
+                             QS.jB.v[1], QS.jT.v[1], QS.jN.v[1], QS.T[0].v[1], QS.B[0].v[1], QS.T[1].v[1], QS.B[1].v[1],
+                             QS.T[2].v[1], QS.B[2].v[1], QS.T[0].v[2], QS.B[0].v[2], QS.T[1].v[2], QS.B[1].v[2], QS.eB.v[2],
+                             QS.T[0].v[3], QS.B[0].v[3], QS.T[1].v[3], QS.B[1].v[3], QS.T[2].v[3], QS.B[2].v[3], QS.T[3].v[3],
+                             QS.B[3].v[3], QS.T[2].v[2], QS.B[2].v[2], QS.eB.v[0]};
+        for (size_t i = 0; i < sizeof(exp_) / sizeof(exp_[0]); i++)
+            if (exp_[i] != got[i]) { if (bad < 5) fprintf(stderr, "it %d: state %zu: %g vs %g\n", it, i, got[i], exp_[i]); bad++; }
+    }
+    return bad;
 }

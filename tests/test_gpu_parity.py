@@ -34,8 +34,16 @@ def g():
     return gnuspeech_amd
 
 
+@pytest.fixture(params=["wide", "quad"])
+def form(request, monkeypatch):
+    """Both kernel forms (include/trm_c_api.h: one voice per lane / four lanes per voice) must meet the
+    same bar; TRM_TUBE_KERNEL steers every launch that is left on TRM_KERNEL_AUTO."""
+    monkeypatch.setenv("TRM_TUBE_KERNEL", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ALL_CASES)
-def test_tube_model_matches_reference_fixture(g, name):
+def test_tube_model_matches_reference_fixture(g, form, name):
     """TRMTubeModel -initWithInputData: / -synthesize on the GPU vs what the reference's C tube produced."""
     gold = golden_io.load(name)
     dl = g.TRMDataList()
@@ -88,19 +96,19 @@ def _batch_vs_oracle(g, pd, voices, tol=RMS_TOL):
     return worst
 
 
-def test_batch_static_vowels_config2(g):
+def test_batch_static_vowels_config2(g, form):
     """BASELINE config 2 shape at a size the oracle finishes in seconds: 96 voices x 0.2 s."""
     fr = cases.config2_frames(96, nframes=51)
     _batch_vs_oracle(g, cases.monet_default_params(44100.0), list(fr))
 
 
-def test_batch_time_varying_config3(g):
+def test_batch_time_varying_config3(g, form):
     """BASELINE config 3 shape: gnuspeech.input tracks with per-voice time/pitch offsets (frication on)."""
     fr = cases.config3_frames(70, nframes=81)            # 70 voices: one full wave + a partial wave
     _batch_vs_oracle(g, cases.monet_default_params(44100.0), list(fr))
 
 
-def test_batch_ragged_config4(g):
+def test_batch_ragged_config4(g, form):
     """BASELINE config 4 shape: ragged utterances in one launch, incl. 0-, 1- and 2-frame voices."""
     voices = cases.config4_frames(20, lo=3, hi=60)
     rows = cases.load_gnuspeech_rows()
@@ -108,7 +116,7 @@ def test_batch_ragged_config4(g):
     _batch_vs_oracle(g, cases.monet_default_params(22050.0), voices)
 
 
-def test_downsampling_batch(g):
+def test_downsampling_batch(g, form):
     """Tube rate above the output rate (short tubes, 22.05 kHz): TRMSampleRateConverter.m:234-297 on the GPU,
     ragged voices, against the oracle."""
     rows = cases.load_gnuspeech_rows()
@@ -119,7 +127,7 @@ def test_downsampling_batch(g):
     _batch_vs_oracle(g, pd, voices)
 
 
-def test_tract_defaults_and_sine(g):
+def test_tract_defaults_and_sine(g, form):
     rows = cases.load_gnuspeech_rows()
     _batch_vs_oracle(g, cases.tract_default_params(), [cases.static_frames(cases.TRACT_VOWEL_FRAME, 21)])
     p = cases.monet_default_params(44100.0)
@@ -191,7 +199,7 @@ def test_synthesizer_facade_and_writers(g, tmp_path):
         assert len(body) == len(ref) and np.max(np.abs(diff)) <= 8
 
 
-def test_device_path_and_int16(g):
+def test_device_path_and_int16(g, form):
     """Device-buffer entry (what bench.py times) == host-buffer entry; int16 normalisation on device."""
     import torch
     pd = cases.monet_default_params(44100.0)
@@ -216,7 +224,7 @@ def test_device_path_and_int16(g):
     assert n >= 2 and t > 0.0
 
 
-def test_full_size_properties(g):
+def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
     batch, and a sampled subset agrees with the oracle."""

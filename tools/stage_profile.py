@@ -19,25 +19,29 @@ import gnuspeech_amd as g  # noqa: E402
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
 wl = sys.argv[3] if len(sys.argv) > 3 else "static"
+form = sys.argv[4] if len(sys.argv) > 4 else "auto"
 nframes = int(round(secs * 250)) + 1
 fr = cases.config2_frames(V, nframes=nframes) if wl == "static" else cases.config3_frames(V, nframes=nframes)
 b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params(44100.0)))
+b.set_kernel(form)
 st = b.prepare_device(fr)
 for _ in range(2):
     b.synthesize_device(st)
 torch.cuda.synchronize()
 L = g.lib()
-nwg = (V + 63) // 64
-NR = 7
+quad = b.last_kernel == "quad"
+nwg = (V + 15) // 16 if quad else (V + 63) // 64
+NR = 5 if quad else 7
 buf = np.zeros(nwg * NR * 8, dtype=np.uint64)
 L.trm_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.trm_debug_stamps(buf.ctypes.data, buf.size) == 0
 s = buf.reshape(nwg, NR, 8).astype(np.float64)
 ntube = (nframes - 1) * b.derived["controlPeriod"] + 26
-names = ["osc", "mix", "coef0", "coef1", "tube", "convert0", "convert1"]
-print("voices %d, %d tube samples; cycles per tube sample (median over %d workgroups)" % (V, ntube, nwg))
+names = ["osc", "mix", "coef", "tube", "convert"] if quad else ["osc", "mix", "coef0", "coef1", "tube", "convert0", "convert1"]
+print("kernel form %s; voices %d, %d tube samples; cycles per tube sample (median over %d workgroups)" % (b.last_kernel, V, ntube, nwg))
 for r in range(NR):
     w, q = np.median(s[:, r, 0]) / ntube, np.median(s[:, r, 1]) / ntube
     print("  %-8s work %7.0f  barrier-wait %7.0f  total %7.0f" % (names[r], w, q, w + q))
-sub = np.median(s[:, 5, 2:], axis=0) / ntube
-print("  convert0 sub-phases (cycles per tube sample): reads-issue %.0f, readlanes %.0f, dot %.0f, stores %.0f, tile+block-end %.0f" % tuple(sub[:5]))
+if not quad:
+    sub = np.median(s[:, 5, 2:], axis=0) / ntube
+    print("  convert0 sub-phases (cycles per tube sample): reads-issue %.0f, readlanes %.0f, dot %.0f, stores %.0f, tile+block-end %.0f" % tuple(sub[:5]))
