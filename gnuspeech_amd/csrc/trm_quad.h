@@ -69,117 +69,146 @@ __device__ __forceinline__ double q_take(double old, double src)
 // Junction Jn sits between sections Sn and Sn+1 and produces T = oT[n] (the top wave entering Sn+1) and
 // B = oB[n-1] (the bottom wave entering Sn) from a = oT[n-1] and b = oB[n] (TRMTubeModel.m:778-853);
 // nasal junction Nn likewise over nT/nB.  Four generic "rounds" r = 0..3 per part:
-//   part 0:  J1  J2  J3  --      + glottis end, nose end (reflection + radiation)
+//   part 0:  J1  J2  J3  --      + glottis end
 //   part 1:  J5  J6  J7  --      + the three-way junction J4;  J6 is the junction-less S6|S7 boundary (k = 0)
-//   part 2:  J8  J9  N5  --      + mouth end, throat
+//   part 2:  J8  J9  --  N5      + BOTH ends (mouth after J9, nose after N5) as one two-wide filter, throat
 //   part 3:  N1  N2  N3  N4
-// The frication band-pass runs in every part (all of them inject its output).
+// The frication band-pass runs in every part (all of them inject its output).  Rounds are stepped two at a
+// time as two-wide values (v_pk_* on the device): rounds (0, 2) and rounds (1, 3), because round r+1 reads
+// round r's T and round r reads round r+1's B: with this pairing the a-inputs of rounds (1, 3) ARE the
+// (T0, T2) pair, the b-inputs of rounds (0, 2) are the (B1, B3) pair, and in part 2 the two ends read the
+// (T1, T3) pair and write the b-inputs of rounds (1, 3).
 struct PartRecord {
-    float kk[4];        // round r's scattering coefficient; slot 3 of parts 1 / 2: alphaU / 1 + C8
-    float tp[4];        // round r's frication tap;          slot 3 of part 1: FC3 (the junction's tap)
+    float kk[4];        // scattering coefficients of rounds 0, 2, 1, 3 (part 1's idle round 3: alphaU)
+    float tp[4];        // frication taps of rounds 0, 2, 1, 3          (part 1's idle round 3: FC3)
 };
 
 TRM_HD void pack_part_records(const Coefs &K, const Const &C, PartRecord R[4])
 {
-    R[0] = PartRecord{{K.k[0], K.k[1], K.k[2], 0.0f}, {0.0f, K.tap[0], K.tap[1], 0.0f}};
-    R[1] = PartRecord{{K.k[3], 0.0f, K.k[4], K.alphaU}, {K.tap[3], K.tap[4], K.tap[5], K.tap[2]}};
-    R[2] = PartRecord{{K.k[5], K.k[6], C.nasalK[3], K.onePlusK8}, {K.tap[6], K.tap[7], 0.0f, 0.0f}};
-    R[3] = PartRecord{{K.nk1, C.nasalK[0], C.nasalK[1], C.nasalK[2]}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    R[0] = PartRecord{{K.k[0], K.k[2], K.k[1], 0.0f}, {0.0f, K.tap[1], K.tap[0], 0.0f}};
+    R[1] = PartRecord{{K.k[3], K.k[4], 0.0f, K.alphaU}, {K.tap[3], K.tap[5], K.tap[4], K.tap[2]}};
+    R[2] = PartRecord{{K.k[5], 0.0f, K.k[6], C.nasalK[3]}, {K.tap[6], 0.0f, K.tap[7], 0.0f}};
+    R[3] = PartRecord{{K.nk1, C.nasalK[1], C.nasalK[0], C.nasalK[2]}, {0.0f, 0.0f, 0.0f, 0.0f}};
 }
+
+// Per-sample coefficients every part reads: the band-pass DOUBLED (y = 2 (alpha (x - x2) + gamma y1 - beta y2),
+// TRMFilters.m:19-29, with the factor folded in: exact in binary floating point) and the end filters'
+// {C8, NC6}, {1 + C8, 1 + NC6} (:820-836, :848-852).
+struct SharedRecord {
+    float bpA2, bpB2, bpG2, pad_;
+    float endK[2], endOnePlus[2];
+};
+
+TRM_HD void pack_shared_record(const Coefs &K, const Const &C, SharedRecord &R)
+{
+    R.bpA2 = 2.0f * K.bpAlpha; R.bpB2 = 2.0f * K.bpBeta; R.bpG2 = 2.0f * K.bpGamma; R.pad_ = 0.0f;
+    R.endK[0] = K.onePlusK8 - 1.0f;     // C8 (near -1 when the mouth closes: no cancellation here)
+    R.endK[1] = C.nasalK[4];
+    R.endOnePlus[0] = K.onePlusK8;
+    R.endOnePlus[1] = C.onePlusNK6;
+}
+
+// two-wide values
+struct Q4P {
+    Q4 x, y;
+};
+inline Q4P operator+(Q4P a, Q4P b) { return Q4P{a.x + b.x, a.y + b.y}; }
+inline Q4P operator-(Q4P a, Q4P b) { return Q4P{a.x - b.x, a.y - b.y}; }
+inline Q4P operator*(Q4P a, Q4P b) { return Q4P{a.x * b.x, a.y * b.y}; }
+inline Q4P pk_make(Q4 x, Q4 y) { return Q4P{x, y}; }
+template <class F> struct PairOf;
+template <> struct PairOf<Q4> { typedef Q4P type; };
+#if defined(__HIP__)
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t pk_make(float x, float y) { return v2f_t{x, y}; }
+template <> struct PairOf<float> { typedef v2f_t type; };
+#endif
 
 template <class F>
 struct QuadState {
-    F T[4], B[4];           // outputs of this part's generic junctions
-    F G;                    // part 0: oT[0], the glottis end
+    typedef typename PairOf<F>::type P;
+    P TA, TB;               // generic junction outputs {T0, T2}, {T1, T3}
+    P BA, BB;               //                          {B0, B2}, {B1, B3}
+    F A0;                   // part 0: oT[0], the glottis end (= round 0's a-input)
     F jT, jB, jN;           // part 1: the three-way junction's oT[4], oB[3], nT[0]
-    F eB;                   // part 2: oB[9] (mouth reflection); part 0: nB[5] (nose reflection)
-    F reflY, radX, radY;    // end filter memories (part 2 mouth, part 0 nose)
+    P eB;                   // part 2: {oB[9], nB[5]}: mouth and nose reflections (= rounds (1, 3)'s b-inputs)
+    P reflY, radX, radY;    // end filter memories {mouth, nose}
     F thY;                  // throat low-pass memory
     F bx1, bx2, by1, by2;   // frication band-pass memory
 };
 
 template <class F>
-struct QuadConst {          // per-part constants of the end filters: part 0 nose, part 2 mouth
-    F endCoeff, endA10, endK, endOnePlus;
-};
-
-template <class F>
 TRM_HD void quad_reset(QuadState<F> &S)
 {
-    for (int i = 0; i < 4; i++) { S.T[i] = F(0.0f); S.B[i] = F(0.0f); }
-    S.G = S.jT = S.jB = S.jN = S.eB = F(0.0f);
-    S.reflY = S.radX = S.radY = S.thY = F(0.0f);
-    S.bx1 = S.bx2 = S.by1 = S.by2 = F(0.0f);
+    const F z = F(0.0f);
+    const typename PairOf<F>::type zz = pk_make(z, z);
+    S.TA = zz; S.TB = zz; S.BA = zz; S.BB = zz;
+    S.A0 = S.jT = S.jB = S.jN = z;
+    S.eB = zz; S.reflY = zz; S.radX = zz; S.radY = zz;
+    S.thY = z;
+    S.bx1 = S.bx2 = S.by1 = S.by2 = z;
 }
 
 // One tube sample.  Returns the tube-rate output in PART 2 (other parts: unspecified).
 template <class F>
-TRM_HD F tube_quad_step(QuadState<F> &S, const QuadConst<F> &Q, const Const &C, F gin, F sig, F thr, F bpAlpha, F bpBeta,
-                        F bpGamma, const F *kk, const F *tp)
+TRM_HD F tube_quad_step(QuadState<F> &S, const Const &C, F gin, F sig, F thr, F bpA2, F bpB2, F bpG2,
+                        typename PairOf<F>::type endK, typename PairOf<F>::type endOnePlus, typename PairOf<F>::type kA,
+                        typename PairOf<F>::type kB, typename PairOf<F>::type tA, typename PairOf<F>::type tB)
 {
+    typedef typename PairOf<F>::type P;
     const F d = F(C.damping);
-    // frication band-pass (TRMFilters.m:19-29)
-    F fr = F(2.0f) * fma_f(bpAlpha, sig - S.bx2, fma_f(bpGamma, S.by1, -(bpBeta * S.by2)));
+    const F fr = fma_f(bpA2, sig - S.bx2, fma_f(bpG2, S.by1, -(bpB2 * S.by2)));
     S.bx2 = S.bx1; S.bx1 = sig; S.by2 = S.by1; S.by1 = fr;
 
     // ---- gather every junction's two inputs from the previous sample's outputs
-    F a0 = S.G;                                   // J1 <- glottis end
-    a0 = q_take<0, kPart1>(a0, S.jT);             // J5 <- three-way oT[4]
-    a0 = q_take<1, kPart2>(a0, S.T[2]);           // J8 <- J7.T (part 1)
-    a0 = q_take<2, kPart3>(a0, S.jN);             // N1 <- three-way nT[0] (part 1)
-    const F b0 = S.B[1];
-    const F a1 = S.T[0];
-    const F b1 = q_take<0, kPart2>(S.B[2], S.eB); // J9 <- mouth reflection oB[9]
-    const F a2 = q_take<3, kPart2>(S.T[1], S.T[3]);   // N5 <- N4.T (part 3)
-    F b2 = S.B[3];                                // N3 <- N4.B
-    b2 = q_take<3, kPart0>(b2, S.jB);             // J3 <- three-way oB[3] (part 1)
-    b2 = q_take<3, kPart1>(b2, S.B[0]);           // J7 <- J8.B (part 2)
-    b2 = q_take<2, kPart2>(b2, S.eB);             // N5 <- nose reflection nB[5] (part 0)
-    const F a3 = S.T[2];
-    const F b3 = q_take<1, kPart3>(S.B[3], S.B[2]);   // N4 <- N5.B (part 2); other parts idle in round 3
-    const F x1 = q_take<1, kPartAll>(S.T[2], S.T[2]); // three-way: oT[3] = J3.T (part 0)
-    const F x2 = S.B[0];                              //            oB[4] = J5.B
-    const F x3 = q_take<2, kPartAll>(S.B[0], S.B[0]); //            nB[0] = N1.B (part 3)
-    const F ei = q_take<2, kPart0>(S.T[1], S.T[2]);   // ends: mouth oT[9] = J9.T; nose nT[5] = N5.T (part 2)
+    F a0 = S.A0;                                   // J1 <- glottis end
+    a0 = q_take<0, kPart1>(a0, S.jT);              // J5 <- three-way oT[4]
+    a0 = q_take<1, kPart2>(a0, S.TA.y);            // J8 <- J7.T (part 1 round 2)
+    a0 = q_take<2, kPart3>(a0, S.jN);              // N1 <- three-way nT[0] (part 1)
+    const F a3 = q_take<3, kPart2>(S.TA.y, S.TB.y);    // round 3 <- own T2; N5 <- N4.T (part 3 round 3)
+    F b2 = S.BB.y;                                 // N3 <- N4.B
+    b2 = q_take<3, kPart0>(b2, S.jB);              // J3 <- three-way oB[3] (part 1)
+    b2 = q_take<3, kPart1>(b2, S.BA.x);            // J7 <- J8.B (part 2 round 0)
+    const F b1 = q_take<0, kPart0 | kPart1 | kPart3>(S.eB.x, S.BA.y);  // round 1 <- own B2; J9 <- mouth reflection oB[9]
+    const F b3 = q_take<1, kPart3>(S.eB.y, S.BB.y);    // N5 <- nose reflection nB[5]; N4 <- N5.B (part 2 round 3)
+    const F x1 = q_take<1, kPartAll>(S.TA.y, S.TA.y);  // three-way: oT[3] = J3.T (part 0 round 2)
+    const F x2 = S.BA.x;                               //            oB[4] = J5.B; also the glottis end's oB[0] = J1.B
+    const F x3 = q_take<2, kPartAll>(S.BA.x, S.BA.x);  //            nB[0] = N1.B (part 3 round 0)
+    const P ei = S.TB;                                 // ends (part 2): mouth oT[9] = J9.T, nose nT[5] = N5.T
+    const P aA = pk_make(a0, S.TB.x), aB = pk_make(S.TA.x, a3);    // a2 = T1, a1 = T0
+    const P bA = pk_make(S.BB.x, b2), bB = pk_make(b1, b3);        // b0 = B1
 
-    // ---- generic junctions (:783-816, :838-846)
-    const F as[4] = {a0, a1, a2, a3}, bs[4] = {b0, b1, b2, b3};
-    for (int r = 0; r < 4; r++) {
-        F dl = kk[r] * (as[r] - bs[r]);
-        S.T[r] = (as[r] + dl) * d + tp[r] * fr;
-        S.B[r] = (bs[r] + dl) * d;
-    }
+    // ---- generic junctions (:783-816, :838-846), two rounds per operation
+    const P dd = pk_make(d, d), ff = pk_make(fr, fr);
+    const P dlA = kA * (aA - bA), dlB = kB * (aB - bB);
+    const P inA = tA * ff, inB = tB * ff;
+    S.TA = (aA + dlA) * dd + inA;
+    S.TB = (aB + dlB) * dd + inB;
+    S.BA = (bA + dlA) * dd;
+    S.BB = (bB + dlB) * dd;
     // ---- glottis end (:781)
-    S.G = x2 * d + gin;
+    S.A0 = x2 * d + gin;
     // ---- three-way junction (:801-806); the three alphas sum to 2 (:733-736)
     {
-        const F aU = kk[3], aLR = fma_f(F(-0.5f), aU, F(1.0f));
+        const F aU = kB.y, aLR = fma_f(F(-0.5f), aU, F(1.0f));
         F jp = aLR * x1 + (aLR * x2 + aU * x3);
         S.jB = (jp - x1) * d;
-        S.jT = (jp - x2) * d + tp[3] * fr;
+        S.jT = (jp - x2) * d + inB.y;
         S.jN = (jp - x3) * d;
     }
-    // ---- mouth / nose ends: reflection + radiation (:820-836, :848-852, TRMFilters.m:47-60)
-    const F onePlus = q_take<0, kPart2>(Q.endOnePlus, kk[3]);
-    const F kend = q_take<0, kPart2>(Q.endK, kk[3] - F(1.0f));   // C8 = (1 + C8) - 1
-    F refl = Q.endA10 * (kend * ei) + Q.endCoeff * S.reflY;
+    // ---- mouth and nose ends: reflection + radiation (:820-836, :848-852, TRMFilters.m:47-60), two-wide
+    const P cf = pk_make(F(C.mCoeff), F(C.nCoeff)), a10 = pk_make(F(C.mA10), F(C.nA10));
+    P refl = a10 * (endK * ei) + cf * S.reflY;
     S.reflY = refl;
-    S.eB = d * refl;
-    F rin = onePlus * ei;
-    F rad = Q.endCoeff * (rin - S.radX + S.radY);
+    S.eB = dd * refl;
+    P rin = endOnePlus * ei;
+    P rad = cf * (rin - S.radX + S.radY);
     S.radX = rin; S.radY = rad;
-    // ---- throat (:341, TRMFilters.m:72-77) and the output sum, in part 2
+    // ---- throat (:341, TRMFilters.m:72-77) and the output sum
     F ty = F(C.ta0) * thr + F(C.tb1) * S.thY;
     S.thY = ty;
-    F out = rad + q_take<2, kPartAll>(rad, rad);     // mouth + nose (part 0)
+    F out = rad.x + rad.y;
     return ty * F(C.throatGain) + out;
-}
-
-// End-filter constants by part.
-TRM_HD void quad_const_parts(const Const &C, float endCoeff[4], float endA10[4], float endK[4], float endOnePlus[4])
-{
-    for (int p = 0; p < 4; p++) { endCoeff[p] = C.mCoeff; endA10[p] = C.mA10; endK[p] = 0.0f; endOnePlus[p] = 1.0f; }
-    endCoeff[0] = C.nCoeff; endA10[0] = C.nA10; endK[0] = C.nasalK[4]; endOnePlus[0] = C.onePlusNK6;
 }
 
 // ================================================================ oscillator, time-slot form

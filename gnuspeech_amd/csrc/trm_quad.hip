@@ -10,7 +10,7 @@
 //   convert          lane = output time, as in the wide kernel (rows of 32 outputs x 2 voices)
 // so one pass of the instruction streams advances 4 tube samples and 256 workgroups cover 4096 voices.
 // One barrier per step of kQB = 4 tube samples; osc works on block i, mix and coef on block i-1, tube on
-// block i-2, convert on whatever is complete, metered.
+// block i-3, convert on whatever is complete, metered.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,14 +28,18 @@ constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
 constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
 constexpr int kOStride = kORing + kOMirror;
 constexpr int kKRec = 8;             // coef -> tube: float4s per (sample, voice): 4 parts x {kk, tp}
+constexpr int kQBufs = 4;           // mix/coef -> tube hand-off buffers: block b lives in buffer b & 3 (the tube stage reads block
+                                     // i-3 and the head of block i-2 while block i-1 is being written)
+constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
+                                     // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
 
 __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const C, const TubeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float2 sO[kQV * kOStride];            // osc -> mix: oscillator reads
     __shared__ __attribute__((aligned(16))) float2 sA[2 * kWave];                 // osc -> mix: {ax, ah1}
-    __shared__ __attribute__((aligned(16))) float4 sX[2 * kWave];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
-    __shared__ __attribute__((aligned(16))) float4 sBP[2 * kWave];                // coef -> tube: band-pass
-    __shared__ __attribute__((aligned(16))) float4 sK[2 * kQB * kKRec * kQV];     // coef -> tube: part records
+    __shared__ __attribute__((aligned(16))) float4 sX[kQBufs * kWave];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
+    __shared__ __attribute__((aligned(16))) float4 sBP[kQBufs * 2 * kWave];            // coef -> tube: SharedRecord [buf][half][slot][voice]
+    __shared__ __attribute__((aligned(16))) float4 sK[kQBufs * kQB * kKRec * kQV];     // coef -> tube: part records
     __shared__ __attribute__((aligned(16))) float sY[kQV * kYStride];             // tube-rate rings
     __shared__ uint4 sInfo[kQV];
     __shared__ float sMx[8 * kWave];
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     const uint32_t inc = C.timeRegisterIncrement;
     const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
-    // the tube stage steps block i-2 at step i; the convert wave finishes what is queued after the last barrier
-    const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 3 : 0;
+    // the tube stage steps block i-3 at step i; the convert wave finishes what is queued after the last barrier
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 4 : 0;
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             STAMP_BEGIN
             if (step >= 1 && (step - 1) * kQB < nTotal) {
                 const uint32_t blk = step - 1;
-                const int buf = blk & 1;
+                const int buf = blk & 1, xbuf = blk & (kQBufs - 1);
                 const uint32_t n0 = blk * kQB;
                 if ((n0 & (kNoiseHalf - 1)) == 0 && n0 > 0) {
                     // entering a noise half: it was requested one half ago; refill the other half
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const float pulse = fir_direct(win, ca, cb);
                 const float2 a = sA[buf * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
-                sX[buf * kWave + part * kQV + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                sX[xbuf * kWave + part * kQV + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
             }
             STAMP_MID
             __syncthreads();
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             if (step >= 1 && (step - 1) * kQB < nTotal) {
-                const int buf = (step - 1) & 1;
+                const int buf = (step - 1) & (kQBufs - 1);
                 if (j >= CP) {
                     j -= CP;
                     per++;
@@ -215,7 +219,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     dst[(2 * p) * kQV] = make_float4(R[p].kk[0], R[p].kk[1], R[p].kk[2], R[p].kk[3]);
                     dst[(2 * p + 1) * kQV] = make_float4(R[p].tp[0], R[p].tp[1], R[p].tp[2], R[p].tp[3]);
                 }
-                sBP[buf * kWave + part * kQV + vq] = make_float4(K.bpAlpha, K.bpBeta, K.bpGamma, 0.0f);
+                SharedRecord H;
+                pack_shared_record(K, C, H);
+                sBP[(buf * 2) * kWave + part * kQV + vq] = make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f);
+                sBP[(buf * 2 + 1) * kWave + part * kQV + vq] = make_float4(H.endK[0], H.endK[1], H.endOnePlus[0], H.endOnePlus[1]);
             }
             STAMP_MID
             __syncthreads();
@@ -226,41 +233,61 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // ------------------------------------------------------------ tube: block i-2 at step i, lane = (voice, part)
         QuadState<float> S;
         quad_reset(S);
-        QuadConst<float> Q;
-        {
-            float a[4], b[4], c[4], e[4];
-            quad_const_parts(C, a, b, c, e);
-            Q.endCoeff = part == 0 ? a[0] : a[2];
-            Q.endA10 = part == 0 ? b[0] : b[2];
-            Q.endK = part == 0 ? c[0] : c[2];
-            Q.endOnePlus = part == 0 ? e[0] : e[2];
-        }
-        float *const ring = &sY[vq * kYStride];
+        float4 *const ring = reinterpret_cast<float4 *>(&sY[vq * kYStride]);
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
+        // one sample's inputs: {gin, sig, thr}, band-pass, end coefficients, this part's record
+        struct In { float4 x, bp, e4, k4, t4; };
+        auto load_in = [&](uint32_t blk, int s) {
+            const int buf = blk & (kQBufs - 1);
+            In r;
+            r.x = sX[buf * kWave + s * kQV + vq];
+            r.bp = sBP[(buf * 2) * kWave + s * kQV + vq];
+            r.e4 = sBP[(buf * 2 + 1) * kWave + s * kQV + vq];
+            const float4 *rec = &sK[((buf * kQB + s) * kKRec + 2 * part) * kQV + vq];
+            r.k4 = rec[0];
+            r.t4 = rec[kQV];
+            return r;
+        };
+        auto step_one = [&](const In &r) {
+            return tube_quad_step<float>(S, C, r.x.x, r.x.y, r.x.z, r.bp.x, r.bp.y, r.bp.z, v2f_t{r.e4.x, r.e4.y},
+                                         v2f_t{r.e4.z, r.e4.w}, v2f_t{r.k4.x, r.k4.y}, v2f_t{r.k4.z, r.k4.w},
+                                         v2f_t{r.t4.x, r.t4.y}, v2f_t{r.t4.z, r.t4.w});
+        };
+        // Block i-3 at step i.  Its first sample's inputs were fetched during step i-1 (block i-3 was complete
+        // by then), the other three are fetched now and land behind the first sample's arithmetic, and the
+        // head of block i-2 is fetched behind the last: no LDS latency is exposed.
+        In head;
+        head.x = head.bp = head.e4 = head.k4 = head.t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 2 && (step - 2) * kQB < nTotal) {
-                const uint32_t blk = step - 2;
-                const int buf = blk & 1;
+            if (step >= 3 && (step - 3) * kQB < nTotal) {
+                const uint32_t blk = step - 3;
+                const uint32_t n0 = blk * kQB;
+                const In i1 = load_in(blk, 1), i2 = load_in(blk, 2), i3 = load_in(blk, 3);
+                float y[kQB];
+                // (samples past nTotal in the last block step on stale inputs; their output is forced to 0)
+                y[0] = step_one(head);
+                y[1] = step_one(i1);
+                y[2] = step_one(i2);
+                head = load_in(blk + 1, 0);
+                y[3] = step_one(i3);
 #pragma unroll
-                for (int s = 0; s < kQB; s++) {
-                    // (samples past nTotal in the last block step on stale inputs; their output is forced to 0)
-                    const uint32_t n = blk * kQB + s;
-                    const float4 x = sX[buf * kWave + s * kQV + vq];
-                    const float4 bp = sBP[buf * kWave + s * kQV + vq];
-                    const float4 *rec = &sK[((buf * kQB + s) * kKRec + 2 * part) * kQV + vq];
-                    const float4 k4 = rec[0], t4 = rec[kQV];
-                    const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, tp[4] = {t4.x, t4.y, t4.z, t4.w};
-                    float y = tube_quad_step<float>(S, Q, C, x.x, x.y, x.z, bp.x, bp.y, bp.z, kk, tp);
-                    y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
-                    if (part == 2) {
-                        const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
-                        ring[slot] = y;
-                        if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;
-                        if (tubeOut && laneValid && n < ntubeLane + 2u * (uint32_t)C.padSize) tubeOut[n] = y;
+                for (int s = 0; s < kQB; s++) y[s] = n0 + s < ntubeLane ? y[s] : 0.0f;   // zero flush / shorter voices
+                if (part == 2) {
+                    // tube sample n sits at ring slot (n + kQLead) & 127: a block is one aligned 16-byte store
+                    const uint32_t slot4 = ((n0 + kQLead) & (kYRing - 1)) >> 2;
+                    const float4 yy = make_float4(y[0], y[1], y[2], y[3]);
+                    ring[slot4] = yy;
+                    if (slot4 < (uint32_t)(kYMirror / 4)) ring[slot4 + kYRing / 4] = yy;
+                    if (tubeOut && laneValid) {
+                        const uint32_t lim = ntubeLane + 2u * (uint32_t)C.padSize;
+                        for (int s = 0; s < kQB; s++)
+                            if (n0 + s < lim) tubeOut[n0 + s] = y[s];
                     }
                 }
+            } else if (step == 2 && nTotal > 0) {
+                head = load_in(0, 0);
             }
             STAMP_MID
             __syncthreads();
@@ -284,10 +311,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // running max |y| per (row, lane): row r = voices 2r (lanes 0-31) and 2r+1 (lanes 32-63)
         for (int r = 0; r < 8; r++) sMx[r * kWave + lane] = 0.0f;
 
+        // output k reads tube samples e-25 .. e, e = src_position(k): ring slots e + kRingShift .. + 25
+        constexpr uint32_t kRingShift = kQLead - (kSrcWindow - 1);
         v2f cc[16];
         auto fetch_row = [&](uint32_t blk) {
             const uint32_t k = blk * kCvtCols + col;
-            const uint32_t off = src_position(k, inc) & 3u;
+            const uint32_t off = (src_position(k, inc) + kRingShift) & 3u;
             const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
             for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
         };
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         uint32_t winBase = 0, kLane = 0, needLast = 0;
         auto begin_block = [&]() {
             kLane = blk * kCvtCols + col;
-            winBase = src_position(kLane, inc) & (kYRing - 1) & ~3u;
+            winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
             fetch_row(blk);
@@ -340,8 +369,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            // visible after the previous barrier: tube samples n < (step-2)*kQB
-            const uint32_t ready = step >= 2 ? (step - 2) * kQB : 0;
+            // visible after the previous barrier: tube samples n < (step-3)*kQB
+            const uint32_t ready = step >= 3 ? (step - 3) * kQB : 0;
             credit += earn;
             if (credit > (4u << 16)) credit = 4u << 16;
             while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {

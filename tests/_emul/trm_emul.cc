@@ -122,13 +122,6 @@ extern "C" int trm_emul_synthesize_quad(const trm_input_params *p, const float *
     double P = 0.0;
     QuadState<Q4> QS;
     quad_reset(QS);
-    QuadConst<Q4> QC;
-    {
-        float a[4], b[4], c[4], e[4];
-        quad_const_parts(C, a, b, c, e);
-        QC.endCoeff = Q4(a[0], a[1], a[2], a[3]); QC.endA10 = Q4(b[0], b[1], b[2], b[3]);
-        QC.endK = Q4(c[0], c[1], c[2], c[3]); QC.endOnePlus = Q4(e[0], e[1], e[2], e[3]);
-    }
     for (size_t n0 = 0; n0 < ntube; n0 += kSlots) {
         // ---- osc: slots in parallel, phase by prefix sum
         double two[kSlots], incs[kSlots], axd[kSlots];
@@ -175,7 +168,11 @@ extern "C" int trm_emul_synthesize_quad(const trm_input_params *p, const float *
                 kk[r] = Q4(R[0].kk[r], R[1].kk[r], R[2].kk[r], R[3].kk[r]);
                 tp[r] = Q4(R[0].tp[r], R[1].tp[r], R[2].tp[r], R[3].tp[r]);
             }
-            Q4 y = tube_quad_step(QS, QC, C, Q4(E.gin), Q4(E.sig), Q4(E.thr), Q4(K.bpAlpha), Q4(K.bpBeta), Q4(K.bpGamma), kk, tp);
+            SharedRecord H;
+            pack_shared_record(K, C, H);
+            Q4 y = tube_quad_step(QS, C, Q4(E.gin), Q4(E.sig), Q4(E.thr), Q4(H.bpA2), Q4(H.bpB2), Q4(H.bpG2),
+                                  Q4P{Q4(H.endK[0]), Q4(H.endK[1])}, Q4P{Q4(H.endOnePlus[0]), Q4(H.endOnePlus[1])},
+                                  Q4P{kk[0], kk[1]}, Q4P{kk[2], kk[3]}, Q4P{tp[0], tp[1]}, Q4P{tp[2], tp[3]});
             if (tube) tube[m] = y.v[2];
             sig[25 + m] = y.v[2];
         }
@@ -207,11 +204,6 @@ extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, uns
     auto rnd = [&]() { return (float)rand() / (float)RAND_MAX * 2.0f - 1.0f; };
     TubeState TS; tube_reset(TS);
     QuadState<Q4> QS; quad_reset(QS);
-    QuadConst<Q4> QC;
-    float a[4], b[4], c[4], e[4];
-    quad_const_parts(C, a, b, c, e);
-    QC.endCoeff = Q4(a[0], a[1], a[2], a[3]); QC.endA10 = Q4(b[0], b[1], b[2], b[3]);
-    QC.endK = Q4(c[0], c[1], c[2], c[3]); QC.endOnePlus = Q4(e[0], e[1], e[2], e[3]);
     int bad = 0;
     for (int it = 0; it < iters; it++) {
         if (it % 200 == 0) { tube_reset(TS); quad_reset(QS); }   // random coefficients are not a passive tube: keep it finite
@@ -233,7 +225,11 @@ extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, uns
             kk[r] = Q4(R[0].kk[r], R[1].kk[r], R[2].kk[r], R[3].kk[r]);
             tp[r] = Q4(R[0].tp[r], R[1].tp[r], R[2].tp[r], R[3].tp[r]);
         }
-        Q4 y = tube_quad_step(QS, QC, C, Q4(E.gin), Q4(E.sig), Q4(E.thr), Q4(K.bpAlpha), Q4(K.bpBeta), Q4(K.bpGamma), kk, tp);
+        SharedRecord H;
+        pack_shared_record(K, C, H);
+        Q4 y = tube_quad_step(QS, C, Q4(E.gin), Q4(E.sig), Q4(E.thr), Q4(H.bpA2), Q4(H.bpB2), Q4(H.bpG2),
+                              Q4P{Q4(H.endK[0]), Q4(H.endK[1])}, Q4P{Q4(H.endOnePlus[0]), Q4(H.endOnePlus[1])},
+                              Q4P{kk[0], kk[1]}, Q4P{kk[2], kk[3]}, Q4P{tp[0], tp[1]}, Q4P{tp[2], tp[3]});
         if (y.v[2] != y0) { if (bad < 5) fprintf(stderr, "it %d: y %g vs %g\n", it, y.v[2], y0); bad++; }
         // state correspondence
         const Waves &w = TS.w;
@@ -241,11 +237,12 @@ extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, uns
                               w.oT[5], w.oB[4], w.oT[6], w.oB[5], w.oT[7], w.oB[6], w.oT[8], w.oB[7], w.oT[9], w.oB[8],
                               w.oB[9], w.nT[1], w.nB[0], w.nT[2], w.nB[1], w.nT[3], w.nB[2], w.nT[4], w.nB[3], w.nT[5],
                               w.nB[4], w.nB[5]};
-        const float got[] = {QS.G.v[0], QS.T[0].v[0], QS.B[0].v[0], QS.T[1].v[0], QS.B[1].v[0], QS.T[2].v[0], QS.B[2].v[0],
-                             QS.jB.v[1], QS.jT.v[1], QS.jN.v[1], QS.T[0].v[1], QS.B[0].v[1], QS.T[1].v[1], QS.B[1].v[1],
-                             QS.T[2].v[1], QS.B[2].v[1], QS.T[0].v[2], QS.B[0].v[2], QS.T[1].v[2], QS.B[1].v[2], QS.eB.v[2],
-                             QS.T[0].v[3], QS.B[0].v[3], QS.T[1].v[3], QS.B[1].v[3], QS.T[2].v[3], QS.B[2].v[3], QS.T[3].v[3],
-                             QS.B[3].v[3], QS.T[2].v[2], QS.B[2].v[2], QS.eB.v[0]};
+        const Q4 T0 = QS.TA.x, T2 = QS.TA.y, T1 = QS.TB.x, T3 = QS.TB.y, B0 = QS.BA.x, B2 = QS.BA.y, B1 = QS.BB.x, B3 = QS.BB.y;
+        const float got[] = {QS.A0.v[0], T0.v[0], B0.v[0], T1.v[0], B1.v[0], T2.v[0], B2.v[0],
+                             QS.jB.v[1], QS.jT.v[1], QS.jN.v[1], T0.v[1], B0.v[1], T1.v[1], B1.v[1],
+                             T2.v[1], B2.v[1], T0.v[2], B0.v[2], T1.v[2], B1.v[2], QS.eB.x.v[2],
+                             T0.v[3], B0.v[3], T1.v[3], B1.v[3], T2.v[3], B2.v[3], T3.v[3],
+                             B3.v[3], T3.v[2], B3.v[2], QS.eB.y.v[2]};
         for (size_t i = 0; i < sizeof(exp_) / sizeof(exp_[0]); i++)
             if (exp_[i] != got[i]) { if (bad < 5) fprintf(stderr, "it %d: state %zu: %g vs %g\n", it, i, got[i], exp_[i]); bad++; }
     }

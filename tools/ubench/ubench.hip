@@ -41,6 +41,16 @@ __global__ void k(unsigned long long *out, float *sink, int nwaves)
                 }
                 if (KIND == 9) asm volatile("v_mov_b32 %0, %0" : "+v"(a[i]));            // v_mov
                 if (KIND == 10) asm volatile("s_nop 0");
+                if (KIND == 11) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a[i]), __builtin_bit_cast(int, a[(i + 1) & 7]), 0x124, 0xF, 0x5, false));   // v_mov_b32_dpp row_ror:4, bank-masked merge
+                if (KIND == 12) {   // fma then a DPP merge of its result (the hazard the quad tube step lives on)
+                    a[i] = __builtin_fmaf(a[i], b, c);
+                    a[(i + 4) & 7] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a[(i + 4) & 7]), __builtin_bit_cast(int, a[i]), 0x128, 0xF, 0x2, false));
+                }
+                if (KIND == 13) {   // scalar fma, explicitly not packed
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                }
+                if (KIND == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));
+                if (KIND == 15) asm volatile("s_add_u32 s20, s20, 1" ::: "s20");
             }
         }
     }
@@ -81,6 +91,11 @@ int main()
         run<8>("ds_read_b128 + 4 v_add", threads, dOut, dSink);
         run<9>("v_mov_b32", threads, dOut, dSink);
         run<10>("s_nop 0", threads, dOut, dSink);
+        run<11>("v_mov_b32_dpp merge", threads, dOut, dSink);
+        run<12>("v_fma + dpp merge (2 instr)", threads, dOut, dSink);
+        run<13>("v_fma_f32 (asm, unpacked)", threads, dOut, dSink);
+        run<14>("v_cndmask_b32", threads, dOut, dSink);
+        run<15>("s_add_u32", threads, dOut, dSink);
     }
     return 0;
 }
