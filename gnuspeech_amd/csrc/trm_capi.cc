@@ -84,7 +84,7 @@ struct trm_batch {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     bool timing = true;
     int kernel = TRM_KERNEL_AUTO;        // trm_batch_set_kernel
-    uint32_t wideThreshold = 32768;      // voices from which the one-voice-per-lane kernel fills the chip twice over
+    uint32_t wideThreshold = 8192;       // voices from which the one-voice-per-lane kernel fills the chip twice over
     int lastKernel = TRM_KERNEL_AUTO;    // what the last launch ran
 };
 
@@ -175,9 +175,10 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipMalloc((void **)&b->dConst, sizeof(trm::Const)));
     B_TRY(hipMemcpy(b->dConst, &b->c, sizeof(trm::Const), hipMemcpyHostToDevice));
     // 4 zero floats in front of row 0: the convert stage fetches rows shifted by up to 3 floats
-    B_TRY(hipMalloc((void **)&b->dRowsAlloc, (rows.size() + 4) * sizeof(float)));
-    B_TRY(hipMemset(b->dRowsAlloc, 0, 4 * sizeof(float)));
-    b->dRows = b->dRowsAlloc + 4;
+    // [64 floats of write-only sink for masked converter lanes][4 zeros in front of row 0][rows]
+    B_TRY(hipMalloc((void **)&b->dRowsAlloc, (rows.size() + 68) * sizeof(float)));
+    B_TRY(hipMemset(b->dRowsAlloc, 0, 68 * sizeof(float)));
+    b->dRows = b->dRowsAlloc + 68;
     B_TRY(hipMemcpy(b->dRows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dSine, sine.size() * sizeof(float)));
     B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -290,6 +291,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     a.sine = b->dSine;
     a.nvoices = (uint32_t)nvoices;
     a.stamps = nullptr;
+    a.sink = b->dRowsAlloc;
     a.tube_out = nullptr;
     a.tube_offset = nullptr;
     if (!b->c.upsample) {

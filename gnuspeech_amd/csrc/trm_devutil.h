@@ -33,6 +33,15 @@ __device__ __forceinline__ void dma4(const float *src, float *ldsBaseUniform)
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// The pipeline's step barrier.  Only LDS traffic crosses it (every hand-off between the waves of a workgroup
+// lives in LDS), so it waits for this wave's LDS operations and NOT for its global stores: __syncthreads()
+// also drains vmcnt, which parks the converter waves (and with them the whole workgroup) behind the
+// acknowledgement of PCM stores nobody in the workgroup reads.
+__device__ __forceinline__ void step_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) {
@@ -45,18 +54,24 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // Diagnostic build only (-DTRM_STAMP, tools/stage_profile.py): per-role cycles spent working vs
 // waiting at the step barrier.  In the product build these macros expand to nothing.
 #ifdef TRM_STAMP
-#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0;
+#ifndef TRM_STAMP_LONG
+#define TRM_STAMP_LONG 1600      /* cycles: a step's work above this counts as a long step */
+#endif
+#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0, st_long = 0, st_excess = 0, st_max = 0;
 #define SUB_DECL unsigned long long sub_t = 0, sub_acc[6] = {0, 0, 0, 0, 0, 0};
 #define SUB_START sub_t = __builtin_readcyclecounter();
 #define SUB_LAP(i_) { unsigned long long n_ = __builtin_readcyclecounter(); sub_acc[i_] += n_ - sub_t; sub_t = n_; }
 #define SUB_STORE(role_) if (lane == 0 && A.stamps) for (int i_ = 0; i_ < 6; i_++) A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 2 + i_] = sub_acc[i_];
 #define STAMP_BEGIN st_t0 = __builtin_readcyclecounter();
-#define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0;
+#define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0; if (st_t1 - st_t0 > TRM_STAMP_LONG) { st_long++; st_excess += st_t1 - st_t0 - TRM_STAMP_LONG; } if (st_t1 - st_t0 > st_max) st_max = st_t1 - st_t0;
 #define STAMP_END st_wait += __builtin_readcyclecounter() - st_t1;
 #define STAMP_STORE(role_)                                                          \
     if (lane == 0 && A.stamps) {                                                    \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8] = st_work;                    \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 1] = st_wait;                \
+        A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 5] = st_long;                \
+        A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 6] = st_excess;              \
+        A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 7] = st_max;                 \
     }
 #else
 #define STAMP_DECL

@@ -32,6 +32,7 @@ struct TubeArgs {
     const uint64_t *tube_offset;
     uint32_t nvoices;
     unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product
+    float *sink;                  // 64 floats nobody reads: where masked converter lanes of trm_tube_kernel_q store
 };
 
 struct ScaleArgs {

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 }
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 }
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 dst[4 * kWave] = make_float4(K.tap[4], K.tap[5], K.tap[6], K.tap[7]);
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 one(wB, wA, buf, 1, blk * kTB + 1);
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
@@ -378,13 +378,13 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             // visible after the previous barrier: tube samples n < (step-2)*kTB
             const uint32_t ready = step >= 2 ? (step - 2) * kTB : 0;
             credit += earn;
-            if (credit > (4u << 16)) credit = 4u << 16;
+            if (credit > (2u << 16)) credit = 2u << 16;   // at most two pairs per step: a ready block is spread over the next steps, not done in a burst
             while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {
                 credit -= 1u << 16;
                 do_pair();
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)

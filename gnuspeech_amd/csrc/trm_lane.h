@@ -337,14 +337,13 @@ TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, co
 }
 
 // Stateless in the sample index: any wave may compute any sample j of the current control period.
-TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
+// Two halves that touch disjoint fields of Coefs (they may run in different waves):
+//   coef_sample_area   radii, velum -> scattering coefficients, three-way junction, NC1
+//   coef_sample_fric   frication volume / position / band -> taps, band-pass coefficients
+TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j)
 {
-    Coefs K;
     const float fj = (float)j;
     // control-rate interpolation (:676-688 evaluated as base + j*delta)
-    float fricDb = fma_f(fj, T.delta[0], T.base[0]);
-    float fricCF = fma_f(fj, T.delta[1], T.base[1]);
-    float fricBW = fma_f(fj, T.delta[2], T.base[2]);
     float r2[8];
     for (int i = 0; i < 8; i++) {
         float r = fma_f(fj, T.delta[3 + i], T.base[3 + i]);
@@ -362,7 +361,14 @@ TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
     K.alphaLR = jsum * r2[3];
     K.alphaU = jsum * v2;
     K.nk1 = (v2 - C.noseR1sq) * rcp_f(v2 + C.noseR1sq);
+}
 
+TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j)
+{
+    const float fj = (float)j;
+    float fricDb = fma_f(fj, T.delta[0], T.base[0]);
+    float fricCF = fma_f(fj, T.delta[1], T.base[1]);
+    float fricBW = fma_f(fj, T.delta[2], T.base[2]);
     // frication taps (:748-773)
     float fricAmp = amplitude_f(fricDb);
     const double fricPos = T.fricPos0 + (double)j * T.fricPosDelta;   // (:676-688), fp64: feeds (int)
@@ -399,6 +405,13 @@ TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
         K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
     }
     K.pad_ = 0.0f;
+}
+
+TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
+{
+    Coefs K;
+    coef_sample_area(K, T, C, j);
+    coef_sample_fric(K, T, C, j);
     return K;
 }
 

@@ -83,12 +83,24 @@ struct PartRecord {
     float tp[4];        // frication taps of rounds 0, 2, 1, 3          (part 1's idle round 3: FC3)
 };
 
+TRM_HD void pack_part_kk(const Coefs &K, const Const &C, PartRecord R[4])      // needs coef_sample_area's fields
+{
+    const float kk[4][4] = {{K.k[0], K.k[2], K.k[1], 0.0f}, {K.k[3], K.k[4], 0.0f, K.alphaU},
+                            {K.k[5], 0.0f, K.k[6], C.nasalK[3]}, {K.nk1, C.nasalK[1], C.nasalK[0], C.nasalK[2]}};
+    for (int p = 0; p < 4; p++)
+        for (int i = 0; i < 4; i++) R[p].kk[i] = kk[p][i];
+}
+TRM_HD void pack_part_tp(const Coefs &K, PartRecord R[4])                       // needs coef_sample_fric's fields
+{
+    const float tp[4][4] = {{0.0f, K.tap[1], K.tap[0], 0.0f}, {K.tap[3], K.tap[5], K.tap[4], K.tap[2]},
+                            {K.tap[6], 0.0f, K.tap[7], 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    for (int p = 0; p < 4; p++)
+        for (int i = 0; i < 4; i++) R[p].tp[i] = tp[p][i];
+}
 TRM_HD void pack_part_records(const Coefs &K, const Const &C, PartRecord R[4])
 {
-    R[0] = PartRecord{{K.k[0], K.k[2], K.k[1], 0.0f}, {0.0f, K.tap[1], K.tap[0], 0.0f}};
-    R[1] = PartRecord{{K.k[3], K.k[4], 0.0f, K.alphaU}, {K.tap[3], K.tap[5], K.tap[4], K.tap[2]}};
-    R[2] = PartRecord{{K.k[5], 0.0f, K.k[6], C.nasalK[3]}, {K.tap[6], 0.0f, K.tap[7], 0.0f}};
-    R[3] = PartRecord{{K.nk1, C.nasalK[1], C.nasalK[0], C.nasalK[2]}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    pack_part_kk(K, C, R);
+    pack_part_tp(K, R);
 }
 
 // Per-sample coefficients every part reads: the band-pass DOUBLED (y = 2 (alpha (x - x2) + gamma y1 - beta y2),
@@ -99,13 +111,21 @@ struct SharedRecord {
     float endK[2], endOnePlus[2];
 };
 
-TRM_HD void pack_shared_record(const Coefs &K, const Const &C, SharedRecord &R)
+TRM_HD void pack_shared_bp(const Coefs &K, SharedRecord &R)                     // coef_sample_fric's fields
 {
     R.bpA2 = 2.0f * K.bpAlpha; R.bpB2 = 2.0f * K.bpBeta; R.bpG2 = 2.0f * K.bpGamma; R.pad_ = 0.0f;
+}
+TRM_HD void pack_shared_end(const Coefs &K, const Const &C, SharedRecord &R)    // coef_sample_area's fields
+{
     R.endK[0] = K.onePlusK8 - 1.0f;     // C8 (near -1 when the mouth closes: no cancellation here)
     R.endK[1] = C.nasalK[4];
     R.endOnePlus[0] = K.onePlusK8;
     R.endOnePlus[1] = C.onePlusNK6;
+}
+TRM_HD void pack_shared_record(const Coefs &K, const Const &C, SharedRecord &R)
+{
+    pack_shared_bp(K, R);
+    pack_shared_end(K, C, R);
 }
 
 // two-wide values

@@ -23,13 +23,16 @@ namespace trm {
 
 constexpr int kQV = 16;              // voices per workgroup
 constexpr int kQB = kSlots;          // tube samples per step = time slots per voice
-constexpr int kQRoles = 5;           // osc, mix, coef, tube, convert
+constexpr int kQRoles = 6;           // osc, mix, coef x2 (area | frication), tube, convert
 constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
 constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
-constexpr int kOStride = kORing + kOMirror;
-constexpr int kKRec = 8;             // coef -> tube: float4s per (sample, voice): 4 parts x {kk, tp}
+constexpr int kOStride = kORing + kOMirror + 2;   // + 16 bytes: the 16 voices' rings start in different LDS banks
+constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
+                                         // + 64 bytes so that the writers' four time slots fall in different LDS banks
+constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
 constexpr int kQBufs = 4;           // mix/coef -> tube hand-off buffers: block b lives in buffer b & 3 (the tube stage reads block
                                      // i-3 and the head of block i-2 while block i-1 is being written)
+constexpr int kRowBufs = 4;          // converter coefficient rows staged in LDS: block B in buffer B & 3
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
                                      // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
 
@@ -37,21 +40,23 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
 {
     __shared__ __attribute__((aligned(16))) float2 sO[kQV * kOStride];            // osc -> mix: oscillator reads
     __shared__ __attribute__((aligned(16))) float2 sA[2 * kWave];                 // osc -> mix: {ax, ah1}
-    __shared__ __attribute__((aligned(16))) float4 sX[kQBufs * kWave];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
-    __shared__ __attribute__((aligned(16))) float4 sBP[kQBufs * 2 * kWave];            // coef -> tube: SharedRecord [buf][half][slot][voice]
-    __shared__ __attribute__((aligned(16))) float4 sK[kQBufs * kQB * kKRec * kQV];     // coef -> tube: part records
+    __shared__ __attribute__((aligned(16))) float4 sX[kQBufs * kQB * kXPitch];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
+    __shared__ __attribute__((aligned(16))) float4 sBP[kQBufs * 2 * kQB * kXPitch];            // coef -> tube: SharedRecord [buf][half][slot][voice]
+    __shared__ __attribute__((aligned(16))) float4 sK[kQBufs * kQB * kKPitch];     // coef -> tube: part records
     __shared__ __attribute__((aligned(16))) float sY[kQV * kYStride];             // tube-rate rings
     __shared__ uint4 sInfo[kQV];
     __shared__ float sMx[8 * kWave];
     __shared__ float sNoise[kNoiseRing];
+    __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kSrcRowC];   // mix -> convert: coefficient rows of 4 blocks
 
     constexpr int kStampRoles = kQRoles;
     (void)kStampRoles;
     const int lane = threadIdx.x & (kWave - 1);
-    // wave -> role: waves w and w+4 share a SIMD; the tube wave (the only serial one) gets a SIMD to itself
+    // wave -> role: waves w and w+4 share a SIMD; the tube wave (the only serial one) gets a SIMD to itself, the
+    // others are paired so that the SIMDs carry about the same work (tools/stage_profile.py)
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifndef TRM_QROLE_PERM
-#define TRM_QROLE_PERM 4, 2, 1, 3, 0      /* convert coef mix tube | osc */
+#define TRM_QROLE_PERM 1, 0, 5, 4, 2, 3      /* mix osc convert tube | coef-area coef-fric */
 #endif
     const int rolePerm[kQRoles] = {TRM_QROLE_PERM};
     int role = 0;
@@ -80,6 +85,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     for (int i = threadIdx.x; i < kQV * kOStride; i += kWave * kQRoles) sO[i] = make_float2(0.0f, 0.0f);
     __syncthreads();
 
+#ifdef TRM_ABL_SKIP      // timing experiments only (tools/bench_variants.sh): the masked roles keep the barriers and do nothing
+    if ((TRM_ABL_SKIP >> role) & 1) {
+        for (uint32_t step = 0; step < nSteps; step++) step_barrier();
+        return;
+    }
+#endif
     if (role == 0) {
         // ------------------------------------------------------------ osc: block i at step i, lane = (voice, slot)
         auto sine = [&](int i) { return sine_table(i); };
@@ -98,6 +109,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             if (step * kQB < nTotal) {
+#ifdef TRM_ABL_NOSETUP
+                if (j >= CP) j -= CP;
+#endif
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
                     j -= CP;
                     per++;
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 sA[(step & 1) * kWave + lane] = make_float2((float)axd, ah1);
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
@@ -141,22 +155,42 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
             dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
         };
-        // window taps of this lane's parity (m & 1 == part & 1: blocks start on multiples of 4)
+        // window taps of this lane's parity (m & 1 == part & 1: blocks start on multiples of 4), as (a, b) pairs
         const int o = part & 1;
-        float ca[kFirWin], cb[kFirWin];
-        for (int i = 0; i < kFirWin; i++) {
-            ca[i] = o ? fir_window_tap_a(C.fir, 1, i) : fir_window_tap_a(C.fir, 0, i);
-            cb[i] = o ? fir_window_tap_b(C.fir, 1, i) : fir_window_tap_b(C.fir, 0, i);
-        }
+        v2f cab[kFirWin];
+        for (int i = 0; i < kFirWin; i++)
+            cab[i] = o ? v2f{fir_window_tap_a(C.fir, 1, i), fir_window_tap_b(C.fir, 1, i)}
+                       : v2f{fir_window_tap_a(C.fir, 0, i), fir_window_tap_b(C.fir, 0, i)};
         if (nSteps > 0) {
             fill_noise_half(0, 0);
             fill_noise_half(kNoiseHalf, 1);
             dma_wait_all();
         }
         const float2 *const ring = &sO[vq * kOStride];
+        // Converter coefficient rows, staged for the convert wave: block B's 32 rows (128 bytes each, shifted per
+        // output like the wide kernel's fetch) are loaded when tube time is within 12 samples of the block's first
+        // output, written to LDS one step later (visible one step after that, >= 4 steps before the convert wave
+        // can begin the block); buffer B & 3 is reused 4 blocks (~57 tube samples) later.
+        uint32_t rowBlk = 0;
+        bool rowsInFlight = false;
+        float4 rq[4];
+        const uint32_t cvtBlocks = C.upsample ? (wave_max_u32(laneValid && nfr > 0 ? (uint32_t)((((uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc) : 0u) + kCvtCols - 1) / kCvtCols : 0;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
+            if (rowsInFlight) {
+                float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) & (kRowBufs - 1)) * (kCvtCols * kSrcRowC) + lane * 16]);
+                for (int q = 0; q < 4; q++) dst[q] = rq[q];
+                rowsInFlight = false;
+            }
+            if (rowBlk < cvtBlocks && src_position(rowBlk * kCvtCols, inc) <= step * kQB + 12u) {
+                const uint32_t k = rowBlk * kCvtCols + ((uint32_t)lane >> 1);
+                const uint32_t off = (src_position(k, inc) + (kQLead - (kSrcWindow - 1))) & 3u;
+                const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off + (lane & 1) * 16;
+                for (int q = 0; q < 4; q++) rq[q] = make_float4(pc[4 * q], pc[4 * q + 1], pc[4 * q + 2], pc[4 * q + 3]);
+                rowsInFlight = true;
+                rowBlk++;
+            }
             if (step >= 1 && (step - 1) * kQB < nTotal) {
                 const uint32_t blk = step - 1;
                 const int buf = blk & 1, xbuf = blk & (kQBufs - 1);
@@ -170,24 +204,36 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 // 26-sample window starting at the even index m - 24 - o (zeros before the first sample)
                 const uint32_t s0 = (m + kORing - 24u - (uint32_t)o) & (kORing - 1);
                 const float4 *wp = reinterpret_cast<const float4 *>(&ring[s0]);
-                float win[2 * kFirWin];
-                for (int q = 0; q < kFirWin / 2; q++) {
-                    const float4 x = wp[q];
-                    win[4 * q] = x.x; win[4 * q + 1] = x.y; win[4 * q + 2] = x.z; win[4 * q + 3] = x.w;
+                // fir_direct's four partial sums as two packed ones: even / odd window slots x (a, b)
+                v2f acc0, acc1;
+                {
+                    const float4 x = wp[0];
+                    acc0 = v2f{x.x, x.y} * cab[0];
+                    acc1 = v2f{x.z, x.w} * cab[1];
                 }
-                const float pulse = fir_direct(win, ca, cb);
+#pragma unroll
+                for (int q = 1; q < kFirWin / 2; q++) {
+                    const float4 x = wp[q];
+                    acc0 = __builtin_elementwise_fma(v2f{x.x, x.y}, cab[2 * q], acc0);
+                    acc1 = __builtin_elementwise_fma(v2f{x.z, x.w}, cab[2 * q + 1], acc1);
+                }
+                acc0 += acc1;
+                const float pulse = acc0.x + acc0.y;
                 const float2 a = sA[buf * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
-                sX[xbuf * kWave + part * kQV + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                sX[(xbuf * kQB + part) * kXPitch + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
         dma_wait_all();
-    } else if (role == 2) {
-        // ------------------------------------------------------------ coef: block i-1 at step i, lane = (voice, slot)
+    } else if (role == 2 || role == 3) {
+        // ------------------------------------------------------------ coef: block i-1 at step i, lane = (voice, slot).
+        // Two waves share the stage by FUNCTION (both are stateless in time): role 2 turns radii and velum into
+        // scattering coefficients, role 3 turns the frication tracks into taps and the band-pass.
+        const bool area = role == 2;
         CoefTrack T;
         float prev[16], cur[16], nxt[16];
         uint32_t per = 0, j = (uint32_t)part;
@@ -202,6 +248,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             STAMP_BEGIN
             if (step >= 1 && (step - 1) * kQB < nTotal) {
                 const int buf = (step - 1) & (kQBufs - 1);
+#ifdef TRM_ABL_NOSETUP
+                if (j >= CP) j -= CP;
+#endif
                 if (j >= CP) {
                     j -= CP;
                     per++;
@@ -209,27 +258,32 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     load_frame(frames, frame_index(per + 2), nxt, 4);
                     coef_track_setup(T, C, prev, cur);
                 }
-                const Coefs K = coef_sample(T, C, (int)j);
-                j += kQB;
+                Coefs K;
                 PartRecord R[4];
-                pack_part_records(K, C, R);
-                // [buf][slot][record quad][voice]
-                float4 *dst = &sK[((buf * kQB + part) * kKRec) * kQV + vq];
-                for (int p = 0; p < 4; p++) {
-                    dst[(2 * p) * kQV] = make_float4(R[p].kk[0], R[p].kk[1], R[p].kk[2], R[p].kk[3]);
-                    dst[(2 * p + 1) * kQV] = make_float4(R[p].tp[0], R[p].tp[1], R[p].tp[2], R[p].tp[3]);
-                }
                 SharedRecord H;
-                pack_shared_record(K, C, H);
-                sBP[(buf * 2) * kWave + part * kQV + vq] = make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f);
-                sBP[(buf * 2 + 1) * kWave + part * kQV + vq] = make_float4(H.endK[0], H.endK[1], H.endOnePlus[0], H.endOnePlus[1]);
+                // [buf][slot]{kk | tp}[the tube wave's lane of (voice, part p)]
+                float4 *dst = &sK[(buf * kQB + part) * kKPitch + (vq >> 2) * 16 + (vq & 3)];
+                if (area) {
+                    coef_sample_area(K, T, C, (int)j);
+                    pack_part_kk(K, C, R);
+                    pack_shared_end(K, C, H);
+                    for (int p = 0; p < 4; p++) dst[p * 4] = make_float4(R[p].kk[0], R[p].kk[1], R[p].kk[2], R[p].kk[3]);
+                    sBP[((buf * 2 + 1) * kQB + part) * kXPitch + vq] = make_float4(H.endK[0], H.endK[1], H.endOnePlus[0], H.endOnePlus[1]);
+                } else {
+                    coef_sample_fric(K, T, C, (int)j);
+                    pack_part_tp(K, R);
+                    pack_shared_bp(K, H);
+                    for (int p = 0; p < 4; p++) dst[kWave + p * 4] = make_float4(R[p].tp[0], R[p].tp[1], R[p].tp[2], R[p].tp[3]);
+                    sBP[((buf * 2) * kQB + part) * kXPitch + vq] = make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f);
+                }
+                j += kQB;
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
-    } else if (role == 3) {
+    } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-2 at step i, lane = (voice, part)
         QuadState<float> S;
         quad_reset(S);
@@ -240,12 +294,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         auto load_in = [&](uint32_t blk, int s) {
             const int buf = blk & (kQBufs - 1);
             In r;
-            r.x = sX[buf * kWave + s * kQV + vq];
-            r.bp = sBP[(buf * 2) * kWave + s * kQV + vq];
-            r.e4 = sBP[(buf * 2 + 1) * kWave + s * kQV + vq];
-            const float4 *rec = &sK[((buf * kQB + s) * kKRec + 2 * part) * kQV + vq];
+            r.x = sX[(buf * kQB + s) * kXPitch + vq];
+            r.bp = sBP[((buf * 2) * kQB + s) * kXPitch + vq];
+            r.e4 = sBP[((buf * 2 + 1) * kQB + s) * kXPitch + vq];
+            const float4 *rec = &sK[(buf * kQB + s) * kKPitch + lane];
             r.k4 = rec[0];
-            r.t4 = rec[kQV];
+            r.t4 = rec[kWave];
             return r;
         };
         auto step_one = [&](const In &r) {
@@ -290,7 +344,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 head = load_in(0, 0);
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
@@ -313,13 +367,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
 
         // output k reads tube samples e-25 .. e, e = src_position(k): ring slots e + kRingShift .. + 25
         constexpr uint32_t kRingShift = kQLead - (kSrcWindow - 1);
+        // Coefficient rows: the mix wave stages every block's 32 rows in LDS several steps ahead (the latency of
+        // global memory would otherwise sit in front of each block's first row pair: this wave's vector-memory
+        // counter also counts its PCM stores); a block begins by copying this lane's row into registers.
         v2f cc[16];
-        auto fetch_row = [&](uint32_t blk) {
-            const uint32_t k = blk * kCvtCols + col;
-            const uint32_t off = (src_position(k, inc) + kRingShift) & 3u;
-            const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
-            for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
-        };
         uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..3) of block `blk`: voices 4*pr .. 4*pr+3
         uint32_t winBase = 0, kLane = 0, needLast = 0;
         auto begin_block = [&]() {
@@ -327,9 +378,14 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            fetch_row(blk);
+            const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk & (kRowBufs - 1)) * (kCvtCols * kSrcRowC) + col * kSrcRowC]);
+            for (int q = 0; q < 8; q++) {
+                const float4 x = row[q];
+                cc[2 * q] = v2f{x.x, x.y};
+                cc[2 * q + 1] = v2f{x.z, x.w};
+            }
         };
-        if (nBlocks > 0) begin_block();
+        bool needBegin = nBlocks > 0;   // block 0's rows are visible from step 2 on
         typedef __attribute__((address_space(1))) float *GlobalFloatPtr;
         typedef __attribute__((address_space(3))) float *LdsFloatPtr;
         // metering (16.16 row pairs per step): a step's kQB tube samples turn into kQB * 2^16/inc outputs per
@@ -341,16 +397,29 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             const int ha = upper ? 1 : 0;
             const float4 *wa = reinterpret_cast<const float4 *>(&sY[(la + ha) * kYStride + winBase]);
             const float4 *wb = reinterpret_cast<const float4 *>(&sY[(lb + ha) * kYStride + winBase]);
-            float4 qa[8], qb[8];
-            for (int q = 0; q < 8; q++) { qa[q] = wa[q]; qb[q] = wb[q]; }
             const uint4 ia = sInfo[la + ha], ib = sInfo[lb + ha];
-            v2f a0 = v2f{qa[0].x, qa[0].y} * cc[0], a1 = v2f{qa[0].z, qa[0].w} * cc[1];
-            v2f b0 = v2f{qb[0].x, qb[0].y} * cc[0], b1 = v2f{qb[0].z, qb[0].w} * cc[1];
-            for (int q = 1; q < 8; q++) {
-                a0 = __builtin_elementwise_fma(v2f{qa[q].x, qa[q].y}, cc[2 * q], a0);
-                a1 = __builtin_elementwise_fma(v2f{qa[q].z, qa[q].w}, cc[2 * q + 1], a1);
-                b0 = __builtin_elementwise_fma(v2f{qb[q].x, qb[q].y}, cc[2 * q], b0);
-                b1 = __builtin_elementwise_fma(v2f{qb[q].z, qb[q].w}, cc[2 * q + 1], b1);
+            // 32-term dot products as packed FMAs: (even, odd) partial sums, two chains per row; the second
+            // row's window is read while the first row's chains run (one row's registers are live at a time)
+            v2f a0, a1, b0, b1;
+            {
+                float4 q[8];
+                for (int i = 0; i < 8; i++) q[i] = wa[i];
+                a0 = v2f{q[0].x, q[0].y} * cc[0];
+                a1 = v2f{q[0].z, q[0].w} * cc[1];
+                for (int i = 1; i < 8; i++) {
+                    a0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], a0);
+                    a1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], a1);
+                }
+            }
+            {
+                float4 q[8];
+                for (int i = 0; i < 8; i++) q[i] = wb[i];
+                b0 = v2f{q[0].x, q[0].y} * cc[0];
+                b1 = v2f{q[0].z, q[0].w} * cc[1];
+                for (int i = 1; i < 8; i++) {
+                    b0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], b0);
+                    b1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], b1);
+                }
             }
             a0 += a1;
             b0 += b1;
@@ -363,7 +432,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             if (++pr == 4) {
                 pr = 0;
                 blk++;
-                if (blk < nBlocks) begin_block();
+                needBegin = blk < nBlocks;
             }
         };
         STAMP_DECL
@@ -372,17 +441,22 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             // visible after the previous barrier: tube samples n < (step-3)*kQB
             const uint32_t ready = step >= 3 ? (step - 3) * kQB : 0;
             credit += earn;
-            if (credit > (4u << 16)) credit = 4u << 16;
-            while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {
+            if (credit > (2u << 16)) credit = 2u << 16;   // at most two pairs per step: a ready block is spread over the next steps, not done in a burst
+            if (needBegin && step >= 2) { begin_block(); needBegin = false; }
+            while (credit >= (1u << 16) && blk < nBlocks && !needBegin && needLast < ready) {
                 credit -= 1u << 16;
                 do_pair();
+                if (needBegin) { begin_block(); needBegin = false; }     // the next block's rows were staged steps ago
             }
             STAMP_MID
-            __syncthreads();
+            step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
-        while (blk < nBlocks) do_pair();
+        while (blk < nBlocks) {
+            if (needBegin) { begin_block(); needBegin = false; }
+            do_pair();
+        }
         float myMax = 0.0f;     // collected by lanes 0..15: voice `lane` of the workgroup
 #pragma unroll
         for (int r = 0; r < 8; r++) {

@@ -31,17 +31,18 @@ torch.cuda.synchronize()
 L = g.lib()
 quad = b.last_kernel == "quad"
 nwg = (V + 15) // 16 if quad else (V + 63) // 64
-NR = 5 if quad else 7
+NR = 6 if quad else 7
 buf = np.zeros(nwg * NR * 8, dtype=np.uint64)
 L.trm_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.trm_debug_stamps(buf.ctypes.data, buf.size) == 0
 s = buf.reshape(nwg, NR, 8).astype(np.float64)
 ntube = (nframes - 1) * b.derived["controlPeriod"] + 26
-names = ["osc", "mix", "coef", "tube", "convert"] if quad else ["osc", "mix", "coef0", "coef1", "tube", "convert0", "convert1"]
+names = ["osc", "mix", "coef0", "coef1", "tube", "convert"] if quad else ["osc", "mix", "coef0", "coef1", "tube", "convert0", "convert1"]
 print("kernel form %s; voices %d, %d tube samples; cycles per tube sample (median over %d workgroups)" % (b.last_kernel, V, ntube, nwg))
 for r in range(NR):
     w, q = np.median(s[:, r, 0]) / ntube, np.median(s[:, r, 1]) / ntube
-    print("  %-8s work %7.0f  barrier-wait %7.0f  total %7.0f" % (names[r], w, q, w + q))
+    nl, ex, mxs = np.median(s[:, r, 5]), np.median(s[:, r, 6]), np.median(s[:, r, 7])
+    print("  %-8s work %7.0f  barrier-wait %7.0f  total %7.0f   long steps %5.0f (excess %6.0f cycles each), longest %6.0f" % (names[r], w, q, w + q, nl, ex / max(nl, 1), mxs))
 if not quad:
     sub = np.median(s[:, 5, 2:], axis=0) / ntube
     print("  convert0 sub-phases (cycles per tube sample): reads-issue %.0f, readlanes %.0f, dot %.0f, stores %.0f, tile+block-end %.0f" % tuple(sub[:5]))
