@@ -51,6 +51,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = __shfl_xor(v, off, kWave);
+        v = o < v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 // Diagnostic build only (-DTRM_STAMP, tools/stage_profile.py): per-role cycles spent working vs
 // waiting at the step barrier.  In the product build these macros expand to nothing.
 #ifdef TRM_STAMP

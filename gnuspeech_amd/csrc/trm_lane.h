@@ -93,13 +93,14 @@ struct Const {
     float breath;               // breathiness/100                           (:210)
     float crossmixFactor;       // 1/amplitude(mixOffset)                    (:213)
     float nasalK[5];            // NC2..NC6, fixed                           (:692-707)
+    float nasalKd[4];           // NC2..NC5 times damping (the junctions' working form, tube_step)
     float onePlusNK6;           // 1 + NC6, formed in double                 (:849)
     float noseR1sq;             // noseRadius[1]^2, for NC1                  (:741)
     float apScaleSq;            // apScale^2, for C8                         (:724)
     // mouth / nose reflection+radiation pairs (TRMFilters.m:34-45): a20 = coeff, a21 = b21 = b11 =
     // -coeff, a10 = 1 - |coeff|
-    float mCoeff, mA10;
-    float nCoeff, nA10;
+    float mCoeff, nCoeff;       // (mouth, nose) pairs: the four-lane kernel filters both ends as one two-wide value
+    float mA10, nA10;
     float ta0, tb1, throatGain;           // throat low-pass                 (TRMFilters.m:64-68)
     float invSampleRate;
     // glottal pulse table geometry (TRMWavetable.m:71-75)
@@ -315,14 +316,14 @@ struct CoefTrack {
 
 struct Coefs {
     float k[8];                 // C1..C8                                   (:712-726)
+    float kd[7], nkd1;          // C1..C7, NC1 times damping: what the junctions multiply by (tube_step)
     float onePlusK8;            // 1 + C8 without cancellation              (:835)
     float alphaLR, alphaU;      // three-way junction                       (:730-736)
     float nk1;                  // NC1                                      (:738-743)
     float tap[8];               // frication taps FC1..FC8                  (:748-773)
     float bpAlpha, bpBeta, bpGamma;   // frication band-pass                (TRMFilters.m:9-17)
-    float pad_;                 // 24 floats = six 16-byte groups
+    float pad_;
 };
-constexpr int kCoefFloats = 24;
 
 // frame columns: 3 fricVol, 4 fricPos, 5 fricCF, 6 fricBW, 7..14 radii, 15 velum
 TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, const float *cur)
@@ -352,7 +353,10 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
     float velum = fma_f(fj, T.delta[11], T.base[11]);
 
     // scattering coefficients (:712-744)
-    for (int i = 0; i < 7; i++) K.k[i] = (r2[i] - r2[i + 1]) * rcp_f(r2[i] + r2[i + 1]);
+    for (int i = 0; i < 7; i++) {
+        K.k[i] = (r2[i] - r2[i + 1]) * rcp_f(r2[i] + r2[i + 1]);
+        K.kd[i] = K.k[i] * C.damping;
+    }
     float rk8 = rcp_f(r2[7] + C.apScaleSq);
     K.k[7] = (r2[7] - C.apScaleSq) * rk8;
     K.onePlusK8 = (r2[7] + r2[7]) * rk8;         // 1 + C8 without the cancellation of a nearly closed mouth
@@ -361,6 +365,7 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
     K.alphaLR = jsum * r2[3];
     K.alphaU = jsum * v2;
     K.nk1 = (v2 - C.noseR1sq) * rcp_f(v2 + C.noseR1sq);
+    K.nkd1 = K.nk1 * C.damping;
 }
 
 TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j)
@@ -464,20 +469,24 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
     float fric = 2.0f * fma_f(K.bpAlpha, E.sig - L.bpX2, fma_f(K.bpGamma, L.bpY1, -(K.bpBeta * L.bpY2)));
     L.bpX2 = L.bpX1; L.bpX1 = E.sig; L.bpY2 = L.bpY1; L.bpY1 = fric;
 
-    const float *k = K.k, *tap = K.tap;
+    // Scattering junction between a (top wave from the left) and b (bottom wave from the right),
+    // (:783-816): T = (a + k (a - b)) d + inj, B = (b + k (a - b)) d, evaluated as
+    // T = d a + (k d)(a - b) + inj, B = d b + (k d)(a - b) with k d formed once per sample by the
+    // coefficient stage: 5 operations instead of 7, same value to rounding.
+    const float *kd = K.kd, *tap = K.tap, *k = K.k;
     const wg_t d = C.damping;
     const wg_t input = E.gin;
     const wg_t fr = fric;
     nw.oT[0] = o.oB[0] * d + input;
     {
-        wg_t dl = k[0] * (o.oT[0] - o.oB[1]);
-        nw.oT[1] = (o.oT[0] + dl) * d;
-        nw.oB[0] = (o.oB[1] + dl) * d;
+        wg_t m = kd[0] * (o.oT[0] - o.oB[1]);
+        nw.oT[1] = fma_f(d, o.oT[0], m);
+        nw.oB[0] = fma_f(d, o.oB[1], m);
     }
     for (int i = 1; i < 3; i++) {             // S2-S3, S3-S4 with taps FC1, FC2
-        wg_t dl = k[i] * (o.oT[i] - o.oB[i + 1]);
-        nw.oT[i + 1] = (o.oT[i] + dl) * d + tap[i - 1] * fr;
-        nw.oB[i] = (o.oB[i + 1] + dl) * d;
+        wg_t m = kd[i] * (o.oT[i] - o.oB[i + 1]);
+        nw.oT[i + 1] = fma_f(d, o.oT[i], m) + tap[i - 1] * fr;
+        nw.oB[i] = fma_f(d, o.oB[i + 1], m);
     }
     {
         wg_t jp = K.alphaLR * o.oT[3] + (K.alphaLR * o.oB[4] + K.alphaU * o.nB[0]);
@@ -486,16 +495,16 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
         nw.nT[0] = (jp - o.nB[0]) * d;
     }
     {
-        wg_t dl = k[3] * (o.oT[4] - o.oB[5]);
-        nw.oT[5] = (o.oT[4] + dl) * d + tap[3] * fr;
-        nw.oB[4] = (o.oB[5] + dl) * d;
+        wg_t m = kd[3] * (o.oT[4] - o.oB[5]);
+        nw.oT[5] = fma_f(d, o.oT[4], m) + tap[3] * fr;
+        nw.oB[4] = fma_f(d, o.oB[5], m);
     }
     nw.oT[6] = o.oT[5] * d + tap[4] * fr;
     nw.oB[5] = o.oB[6] * d;
     for (int i = 6; i < 9; i++) {             // S7-S8, S8-S9, S9-S10 with taps FC6..FC8
-        wg_t dl = k[i - 2] * (o.oT[i] - o.oB[i + 1]);
-        nw.oT[i + 1] = (o.oT[i] + dl) * d + tap[i - 1] * fr;
-        nw.oB[i] = (o.oB[i + 1] + dl) * d;
+        wg_t m = kd[i - 2] * (o.oT[i] - o.oB[i + 1]);
+        nw.oT[i + 1] = fma_f(d, o.oT[i], m) + tap[i - 1] * fr;
+        nw.oB[i] = fma_f(d, o.oB[i + 1], m);
     }
     wg_t out;
     {   // mouth: reflection y = a10*x - b11*y1, radiation y = a20*x + a21*x1 - b21*y1 (TRMFilters.m:47-60)
@@ -508,11 +517,11 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
         out = rad;
     }
     {
-        float kk[5] = {K.nk1, C.nasalK[0], C.nasalK[1], C.nasalK[2], C.nasalK[3]};
+        float kk[5] = {K.nkd1, C.nasalKd[0], C.nasalKd[1], C.nasalKd[2], C.nasalKd[3]};
         for (int i = 0; i < 5; i++) {
-            wg_t dl = kk[i] * (o.nT[i] - o.nB[i + 1]);
-            nw.nT[i + 1] = (o.nT[i] + dl) * d;
-            nw.nB[i] = (o.nB[i + 1] + dl) * d;
+            wg_t m = kk[i] * (o.nT[i] - o.nB[i + 1]);
+            nw.nT[i + 1] = fma_f(d, o.nT[i], m);
+            nw.nB[i] = fma_f(d, o.nB[i + 1], m);
         }
         wg_t refl = C.nA10 * (C.nasalK[4] * o.nT[5]) + C.nCoeff * L.nReflY;
         L.nReflY = refl;

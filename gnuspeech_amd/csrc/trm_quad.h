@@ -79,14 +79,15 @@ __device__ __forceinline__ double q_take(double old, double src)
 // (T0, T2) pair, the b-inputs of rounds (0, 2) are the (B1, B3) pair, and in part 2 the two ends read the
 // (T1, T3) pair and write the b-inputs of rounds (1, 3).
 struct PartRecord {
-    float kk[4];        // scattering coefficients of rounds 0, 2, 1, 3 (part 1's idle round 3: alphaU)
+    float kk[4];        // scattering coefficients x damping of rounds 0, 2, 1, 3 (part 1's idle round 3: alphaU)
     float tp[4];        // frication taps of rounds 0, 2, 1, 3          (part 1's idle round 3: FC3)
 };
 
 TRM_HD void pack_part_kk(const Coefs &K, const Const &C, PartRecord R[4])      // needs coef_sample_area's fields
 {
-    const float kk[4][4] = {{K.k[0], K.k[2], K.k[1], 0.0f}, {K.k[3], K.k[4], 0.0f, K.alphaU},
-                            {K.k[5], 0.0f, K.k[6], C.nasalK[3]}, {K.nk1, C.nasalK[1], C.nasalK[0], C.nasalK[2]}};
+    // (junction coefficients as k * damping: tube_step's working form)
+    const float kk[4][4] = {{K.kd[0], K.kd[2], K.kd[1], 0.0f}, {K.kd[3], K.kd[4], 0.0f, K.alphaU},
+                            {K.kd[5], 0.0f, K.kd[6], C.nasalKd[3]}, {K.nkd1, C.nasalKd[1], C.nasalKd[0], C.nasalKd[2]}};
     for (int p = 0; p < 4; p++)
         for (int i = 0; i < 4; i++) R[p].kk[i] = kk[p][i];
 }
@@ -136,11 +137,13 @@ inline Q4P operator+(Q4P a, Q4P b) { return Q4P{a.x + b.x, a.y + b.y}; }
 inline Q4P operator-(Q4P a, Q4P b) { return Q4P{a.x - b.x, a.y - b.y}; }
 inline Q4P operator*(Q4P a, Q4P b) { return Q4P{a.x * b.x, a.y * b.y}; }
 inline Q4P pk_make(Q4 x, Q4 y) { return Q4P{x, y}; }
+inline Q4P pk_fma(Q4P a, Q4P b, Q4P c) { return Q4P{fma_f(a.x, b.x, c.x), fma_f(a.y, b.y, c.y)}; }
 template <class F> struct PairOf;
 template <> struct PairOf<Q4> { typedef Q4P type; };
 #if defined(__HIP__)
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f_t pk_make(float x, float y) { return v2f_t{x, y}; }
+__device__ __forceinline__ v2f_t pk_fma(v2f_t a, v2f_t b, v2f_t c) { return __builtin_elementwise_fma(a, b, c); }
 template <> struct PairOf<float> { typedef v2f_t type; };
 #endif
 
@@ -200,12 +203,13 @@ TRM_HD F tube_quad_step(QuadState<F> &S, const Const &C, F gin, F sig, F thr, F 
 
     // ---- generic junctions (:783-816, :838-846), two rounds per operation
     const P dd = pk_make(d, d), ff = pk_make(fr, fr);
-    const P dlA = kA * (aA - bA), dlB = kB * (aB - bB);
+    // T = d a + (k d)(a - b) + tap fr, B = d b + (k d)(a - b): kA / kB carry k d (tube_step)
+    const P mA = kA * (aA - bA), mB = kB * (aB - bB);
     const P inA = tA * ff, inB = tB * ff;
-    S.TA = (aA + dlA) * dd + inA;
-    S.TB = (aB + dlB) * dd + inB;
-    S.BA = (bA + dlA) * dd;
-    S.BB = (bB + dlB) * dd;
+    S.TA = pk_fma(dd, aA, mA) + inA;
+    S.TB = pk_fma(dd, aB, mB) + inB;
+    S.BA = pk_fma(dd, bA, mA);
+    S.BB = pk_fma(dd, bB, mB);
     // ---- glottis end (:781)
     S.A0 = x2 * d + gin;
     // ---- three-way junction (:801-806); the three alphas sum to 2 (:733-736)

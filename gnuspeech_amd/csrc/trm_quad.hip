@@ -79,6 +79,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 4 : 0;
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
+    const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
     auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
 
     for (int i = threadIdx.x; i < kQV * kYStride; i += kWave * kQRoles) sY[i] = 0.0f;
@@ -326,8 +327,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 y[2] = step_one(i2);
                 head = load_in(blk + 1, 0);
                 y[3] = step_one(i3);
+                if (n0 + kQB > ntubeMin) {     // (uniform) zero flush / voices shorter than the group's longest
 #pragma unroll
-                for (int s = 0; s < kQB; s++) y[s] = n0 + s < ntubeLane ? y[s] : 0.0f;   // zero flush / shorter voices
+                    for (int s = 0; s < kQB; s++) y[s] = n0 + s < ntubeLane ? y[s] : 0.0f;
+                }
                 if (part == 2) {
                     // tube sample n sits at ring slot (n + kQLead) & 127: a block is one aligned 16-byte store
                     const uint32_t slot4 = ((n0 + kQLead) & (kYRing - 1)) >> 2;
