@@ -30,9 +30,9 @@ constexpr int kOStride = kORing + kOMirror + 2;   // + 16 bytes: the 16 voices' 
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
-constexpr int kQBufs = 4;           // mix/coef -> tube hand-off buffers: block b lives in buffer b & 3 (the tube stage reads block
+constexpr int kQBufs = 3;           // mix/coef -> tube hand-off buffers: block b lives in buffer b % 3 (the tube stage reads block
                                      // i-3 and the head of block i-2 while block i-1 is being written)
-constexpr int kRowBufs = 4;          // converter coefficient rows staged in LDS: block B in buffer B & 3
+constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS: block B in buffer B % 3
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
                                      // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
 
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     __shared__ uint4 sInfo[kQV];
     __shared__ float sMx[8 * kWave];
     __shared__ float sNoise[kNoiseRing];
-    __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kSrcRowC];   // mix -> convert: coefficient rows of 4 blocks
+    __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kSrcRowC];   // mix -> convert: coefficient rows of 3 blocks
 
     constexpr int kStampRoles = kQRoles;
     (void)kStampRoles;
@@ -169,9 +169,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         }
         const float2 *const ring = &sO[vq * kOStride];
         // Converter coefficient rows, staged for the convert wave: block B's 32 rows (128 bytes each, shifted per
-        // output like the wide kernel's fetch) are loaded when tube time is within 12 samples of the block's first
-        // output, written to LDS one step later (visible one step after that, >= 4 steps before the convert wave
-        // can begin the block); buffer B & 3 is reused 4 blocks (~57 tube samples) later.
+        // output like the wide kernel's fetch) are loaded when the oscillator (4 tube samples per step, 3 steps
+        // ahead of the tube stage) is within 4 samples of the block's first output, written to LDS one step later
+        // and visible one step after that: >= 2 steps before the convert wave can begin the block (it needs the
+        // block's predecessor complete: tube time past the block's first output), and buffer B % 3 is rewritten
+        // 3 blocks (~43 tube samples, ~11 steps) later, >= 5 steps after the convert wave copied its row.
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
         float4 rq[4];
@@ -180,11 +182,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             if (rowsInFlight) {
-                float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) & (kRowBufs - 1)) * (kCvtCols * kSrcRowC) + lane * 16]);
+                float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) % kRowBufs) * (kCvtCols * kSrcRowC) + lane * 16]);
                 for (int q = 0; q < 4; q++) dst[q] = rq[q];
                 rowsInFlight = false;
             }
-            if (rowBlk < cvtBlocks && src_position(rowBlk * kCvtCols, inc) <= step * kQB + 12u) {
+            if (rowBlk < cvtBlocks && src_position(rowBlk * kCvtCols, inc) <= step * kQB + 4u) {
                 const uint32_t k = rowBlk * kCvtCols + ((uint32_t)lane >> 1);
                 const uint32_t off = (src_position(k, inc) + (kQLead - (kSrcWindow - 1))) & 3u;
                 const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off + (lane & 1) * 16;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             }
             if (step >= 1 && (step - 1) * kQB < nTotal) {
                 const uint32_t blk = step - 1;
-                const int buf = blk & 1, xbuf = blk & (kQBufs - 1);
+                const int buf = blk & 1, xbuf = blk % kQBufs;
                 const uint32_t n0 = blk * kQB;
                 if ((n0 & (kNoiseHalf - 1)) == 0 && n0 > 0) {
                     // entering a noise half: it was requested one half ago; refill the other half
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             if (step >= 1 && (step - 1) * kQB < nTotal) {
-                const int buf = (step - 1) & (kQBufs - 1);
+                const int buf = (step - 1) % kQBufs;
 #ifdef TRM_ABL_NOSETUP
                 if (j >= CP) j -= CP;
 #endif
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // one sample's inputs: {gin, sig, thr}, band-pass, end coefficients, this part's record
         struct In { float4 x, bp, e4, k4, t4; };
         auto load_in = [&](uint32_t blk, int s) {
-            const int buf = blk & (kQBufs - 1);
+            const int buf = blk % kQBufs;
             In r;
             r.x = sX[(buf * kQB + s) * kXPitch + vq];
             r.bp = sBP[((buf * 2) * kQB + s) * kXPitch + vq];
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk & (kRowBufs - 1)) * (kCvtCols * kSrcRowC) + col * kSrcRowC]);
+            const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk % kRowBufs) * (kCvtCols * kSrcRowC) + col * kSrcRowC]);
             for (int q = 0; q < 8; q++) {
                 const float4 x = row[q];
                 cc[2 * q] = v2f{x.x, x.y};
