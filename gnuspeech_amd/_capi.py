@@ -36,6 +36,13 @@ class TrmParameters(C.Structure):
     ]
 
 
+class TrmIntonation(C.Structure):
+    """trm_intonation (include/trm_c_api.h): MMIntonation's switches + pitch mean + time range."""
+    _fields_ = [("useMicroIntonation", C.c_int32), ("useMacroIntonation", C.c_int32), ("useSmoothIntonation", C.c_int32),
+                ("useDrift", C.c_int32), ("driftDeviation", C.c_float), ("driftCutoff", C.c_float), ("pitchMean", C.c_double),
+                ("timeQuantization", C.c_uint32), ("startTime_ms", C.c_uint32), ("endTime_ms", C.c_uint32)]
+
+
 class TrmDerived(C.Structure):
     _fields_ = [
         ("controlPeriod", C.c_int32), ("sampleRate", C.c_int32), ("actualTubeLength", C.c_double),
@@ -53,8 +60,9 @@ EXPORTS = [
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
+    "trm_events_count_frames", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
     "trm_batch_set_kernel", "trm_batch_last_kernel",
-    "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu",
+    "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
 ]
 
 _lib = None
@@ -115,7 +123,11 @@ def lib():
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]
     L.trm_batch_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.trm_events_count_frames.argtypes = [vp, C.c_size_t, C.POINTER(TrmIntonation), C.POINTER(C.c_size_t)]
+    L.trm_batch_generate_frames_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.POINTER(TrmIntonation), vp, vp, vp, vp]
+    L.trm_batch_generate_frames_host.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(TrmIntonation), vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.trm_batch_set_kernel.argtypes = [vp, C.c_int]
+    L.trm_kernel_blocks_per_cu_form.argtypes = [C.c_int]
     L.trm_batch_last_kernel.argtypes = [vp]
     L.trm_batch_noise_table.argtypes = [vp, vp, C.c_size_t]
     for name in EXPORTS:

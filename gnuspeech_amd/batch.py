@@ -93,6 +93,44 @@ class TRMBatch:
             "max_sample": torch.zeros(max(1, V), dtype=torch.float32, device=dev),
         }
 
+    def prepare_events_device(self, event_lists, settings, device="cuda"):
+        """Upload a batch of event lists (list of (times u32[n], values f64[n,36])); the frames buffer is sized
+        by trm_events_count_frames and filled on the device by generate_frames_device().  The returned state
+        is what synthesize_device() takes: event lists -> PCM without the frames crossing PCIe."""
+        import torch
+        V = len(event_lists)
+        nev = np.array([len(t) for t, _ in event_lists], dtype=np.int64)
+        times = np.concatenate([np.asarray(t, dtype=np.uint32) for t, _ in event_lists]) if V else np.zeros(0, np.uint32)
+        values = (np.concatenate([np.asarray(v, dtype=np.float64).reshape(-1, 36) for _, v in event_lists])
+                  if V else np.zeros((0, 36)))
+        eoff = np.zeros(max(1, V), dtype=np.int64)
+        if V > 1:
+            eoff[1:V] = np.cumsum(nev[:-1])
+        nfr = np.zeros(max(1, V), dtype=np.int64)
+        for v, (t, _) in enumerate(event_lists):
+            n = C.c_size_t()
+            t32 = np.ascontiguousarray(t, dtype=np.uint32)
+            check(lib().trm_events_count_frames(t32.ctypes.data, len(t32), C.byref(settings), C.byref(n)))
+            nfr[v] = n.value
+        st = self.prepare_device([np.zeros((int(n), 16), np.float32) for n in nfr[:V]], device=device)
+        dev = torch.device(device)
+        st["settings"] = settings
+        st["event_times"] = torch.from_numpy(times.astype(np.int32) if times.size else np.zeros(1, np.int32)).to(dev)
+        st["event_values"] = torch.from_numpy(values if values.size else np.zeros((1, 36))).to(dev)
+        st["event_offset"] = torch.from_numpy(eoff).to(dev)
+        st["nevents"] = torch.from_numpy(nev.astype(np.int32) if V else np.zeros(1, np.int32)).to(dev)
+        st["nframes_generated"] = torch.zeros(max(1, V), dtype=torch.int32, device=dev)
+        return st
+
+    def generate_frames_device(self, st, stream=None):
+        """trm_tracks_kernel over a resident batch of event lists: fills st["frames"]."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        check(lib().trm_batch_generate_frames_device(
+            self._h, st["V"], st["event_times"].data_ptr(), st["event_values"].data_ptr(), st["event_offset"].data_ptr(),
+            st["nevents"].data_ptr(), C.byref(st["settings"]), st["frames"].data_ptr(), st["frame_offset"].data_ptr(),
+            st["nframes_generated"].data_ptr(), C.c_void_p(s.cuda_stream)))
+
     def synthesize_device(self, st, stream=None):
         """One pass of the hot path over a resident batch; asynchronous on `stream`
         (default: torch's current stream)."""

@@ -127,6 +127,10 @@ int trm_device_count(void)
 const char *trm_build_info(void) { return "libtrm_hip gfx950 (one tube per lane, wave64) " __DATE__; }
 
 int trm_kernel_blocks_per_cu(void) { return trm::tube_kernel_blocks_per_cu(); }
+int trm_kernel_blocks_per_cu_form(int kernel)
+{
+    return kernel == TRM_KERNEL_QUAD ? trm::tube_quad_kernel_blocks_per_cu() : trm::tube_kernel_blocks_per_cu();
+}
 
 void trm_free(void *p) { free(p); }
 
@@ -446,6 +450,88 @@ int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames,
     HIP_TRY(hipMemcpyAsync(number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return TRM_OK;
+}
+
+// ------------------------------------------------------------------ control-track generation
+int trm_events_count_frames(const uint32_t *times, size_t n, const trm_intonation *s, size_t *nframes)
+{
+    if (!s || !nframes || (n && !times)) return fail(TRM_EINVAL, "null argument");
+    *nframes = 0;
+    if (n < 2) return TRM_OK;
+    uint64_t start = s->startTime_ms, end = s->endTime_ms;
+    if (start == 0 && end == 0) end = ~0ull;                      // EventList.m:892-894
+    size_t i = 1, count = 0;
+    uint64_t t = 0, nextTime = times[1];
+    while (i < n) {                                               // the time stepping of EventList.m:970-1027
+        if (t >= start && t <= end) count++;
+        t += 4;
+        if (t >= nextTime) {
+            i++;
+            if (i == n) break;
+            nextTime = times[i];
+        }
+    }
+    *nframes = count;
+    return TRM_OK;
+}
+
+int trm_batch_generate_frames_device(trm_batch *b, size_t nvoices, const uint32_t *d_event_times, const double *d_event_values,
+                                     const uint64_t *d_event_offset, const uint32_t *d_nevents, const trm_intonation *settings,
+                                     float *d_frames, const uint64_t *d_frame_offset, uint32_t *d_nframes_out, void *stream_)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (nvoices == 0) return TRM_OK;
+    if (!d_event_times || !d_event_values || !d_event_offset || !d_nevents || !settings || !d_frames || !d_frame_offset || !d_nframes_out)
+        return fail(TRM_EINVAL, "null pointer");
+    if (nvoices > 0x7FFFFFFFull) return fail(TRM_EINVAL, "too many voices");
+    HIP_TRY(hipSetDevice(b->device));
+    trm::TrackArgs a;
+    a.event_times = d_event_times;
+    a.event_values = d_event_values;
+    a.event_offset = d_event_offset;
+    a.nevents = d_nevents;
+    a.frames = d_frames;
+    a.frame_offset = d_frame_offset;
+    a.nframes_out = d_nframes_out;
+    a.settings = *settings;
+    a.nvoices = (uint32_t)nvoices;
+    HIP_TRY(trm::launch_tracks(a, (hipStream_t)stream_));
+    return TRM_OK;
+}
+
+int trm_batch_generate_frames_host(trm_batch *b, const uint32_t *times, const double *values, size_t nevents,
+                                   const trm_intonation *settings, float *frames_out, size_t frames_cap, size_t *nframes)
+{
+    if (!b || !settings || !nframes || (nevents && (!times || !values))) return fail(TRM_EINVAL, "null argument");
+    size_t want = 0;
+    int rc = trm_events_count_frames(times, nevents, settings, &want);
+    if (rc) return rc;
+    *nframes = want;
+    if (want == 0) return TRM_OK;
+    if (!frames_out || frames_cap < want) return fail(TRM_EINVAL, "frame buffer holds %zu rows, %zu needed", frames_cap, want);
+    HIP_TRY(hipSetDevice(b->device));
+    DevBuf<uint32_t> dT, dN;
+    DevBuf<double> dV;
+    DevBuf<uint64_t> dOff;
+    DevBuf<float> dF;
+    if ((rc = dT.reserve(nevents)) || (rc = dV.reserve(nevents * TRM_EVENT_VALUES)) || (rc = dOff.reserve(2)) || (rc = dN.reserve(2)) ||
+        (rc = dF.reserve(want * 16)))
+        return rc;
+    const uint64_t zero2[2] = {0, 0};
+    const uint32_t ne = (uint32_t)nevents;
+    hipStream_t st = b->stream;
+    HIP_TRY(hipMemcpyAsync(dT.p, times, nevents * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dV.p, values, nevents * TRM_EVENT_VALUES * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dOff.p, zero2, sizeof zero2, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dN.p, &ne, sizeof ne, hipMemcpyHostToDevice, st));
+    rc = trm_batch_generate_frames_device(b, 1, dT.p, dV.p, dOff.p, dN.p, settings, dF.p, dOff.p + 1, dN.p + 1, st);
+    if (rc) return rc;
+    uint32_t got = 0;
+    HIP_TRY(hipMemcpyAsync(&got, dN.p + 1, sizeof got, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(frames_out, dF.p, want * 16 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (got != want) return fail(TRM_EHIP, "generator wrote %u frames, %zu expected", got, want);
     return TRM_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "../../include/trm_c_api.h"
 #include "trm_lane.h"
 
 namespace trm {
@@ -67,5 +68,19 @@ struct DownArgs {
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
+
+// Control-track generation (trm_tracks.hip): event lists -> 16-column frames, one wave per utterance.
+struct TrackArgs {
+    const uint32_t *event_times;      // u32 [sum nevents]
+    const double *event_values;       // f64 [sum nevents][36], NaN = absent
+    const uint64_t *event_offset;     // first event of voice v
+    const uint32_t *nevents;
+    float *frames;                    // f32 [sum nframes][16]
+    const uint64_t *frame_offset;     // first frame row of voice v
+    uint32_t *nframes_out;
+    trm_intonation settings;
+    uint32_t nvoices;
+};
+hipError_t launch_tracks(const TrackArgs &a, hipStream_t stream);
 
 }  // namespace trm

@@ -188,6 +188,54 @@ int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,
                                      const uint32_t *d_number_samples, const float *d_max_sample,
                                      int16_t *d_int16, int for_wav_data, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Control-track generation at 250 Hz: the step in front of the tube.
+ * Replaces -[EventList generateOutputInTimeRange:forSynthesizer:parameterLogger:]
+ * (Frameworks/GnuSpeech/MonetModel/EventList.m:883-1061) with MMDriftGenerator -generateDrift
+ * (MMDriftGenerator.m:65-78): piece-wise linear interpolation of an utterance's event list
+ * (events = time in ms + 36 values, NaN = "no target here") into the 16-column frames the tube
+ * consumes, one frame every 4 ms.  On the device the frames land directly in the tube's frame
+ * buffer, so a batch goes from event lists to PCM without the frames ever crossing PCIe.
+ * Values 0..15 are the tube parameters, 16..31 their special-event offsets, 32 the intonation
+ * contour (semitones), 33..35 the smooth-intonation slopes (EventList.m:931-959, 1045-1053). */
+#define TRM_EVENT_VALUES 36
+
+typedef struct trm_intonation {
+    int32_t useMicroIntonation;    /* MMIntonation.h:11; off -> table[0] starts from 0 (EventList.m:974-975) */
+    int32_t useMacroIntonation;    /* :10; adds the contour, value 32                      (EventList.m:978-981) */
+    int32_t useSmoothIntonation;   /* :12; contour advanced by the cubic slopes 33..35     (EventList.m:1012-1015) */
+    int32_t useDrift;              /* :14; adds MMDriftGenerator's low-passed noise        (EventList.m:976-977) */
+    float   driftDeviation;        /* :15 semitones */
+    float   driftCutoff;           /* :16 Hz */
+    double  pitchMean;             /* MMSynthesisParameters.h:34 `pitch`, added last       (EventList.m:983) */
+    uint32_t timeQuantization;     /* ms; the drift generator's rate is 1000 / this        (EventList.m:903) */
+    uint32_t startTime_ms;         /* the time range: frames are emitted for start <= t <= end; */
+    uint32_t endTime_ms;           /*   end == 0 and start == 0 means "everything"         (EventList.m:892-899) */
+} trm_intonation;
+
+/* Number of frames the generator emits for an event list with these event times (exact: follows the
+ * loop's time stepping, EventList.m:979-1027).  nevents < 2 -> 0 (the reference indexes event 1). */
+int  trm_events_count_frames(const uint32_t *event_times, size_t nevents, const trm_intonation *settings,
+                             size_t *nframes);
+
+/* Device entry.  Layout in HBM:
+ *   d_event_times   u32 [sum nevents]        voice v owns entries event_offset[v] .. +nevents[v]
+ *   d_event_values  f64 [sum nevents][36]    same indexing, NaN = absent
+ *   d_frames        f32 [sum nframes][16]    voice v writes rows frame_offset[v] .. +nframes[v] where
+ *                                            nframes[v] = trm_events_count_frames(...) (the caller sizes it)
+ * One settings struct for the whole batch.  d_nframes_out[v] receives the number of rows written. */
+int  trm_batch_generate_frames_device(trm_batch *batch, size_t nvoices,
+                                      const uint32_t *d_event_times, const double *d_event_values,
+                                      const uint64_t *d_event_offset, const uint32_t *d_nevents,
+                                      const trm_intonation *settings,
+                                      float *d_frames, const uint64_t *d_frame_offset, uint32_t *d_nframes_out,
+                                      void *stream);
+
+/* Host-buffer form of one utterance (H2D + kernel + D2H): frames_out has room for frames_cap rows. */
+int  trm_batch_generate_frames_host(trm_batch *batch, const uint32_t *event_times, const double *event_values,
+                                    size_t nevents, const trm_intonation *settings,
+                                    float *frames_out, size_t frames_cap, size_t *nframes);
+
 /* Kernel form of the synthesis launch.  Both forms compute the same samples (same arithmetic per value);
  * they differ in how a voice is laid out on the machine:
  *   TRM_KERNEL_WIDE  one voice per lane, 64 voices per workgroup: highest throughput once the batch fills
@@ -212,6 +260,8 @@ int  trm_device_count(void);
 const char *trm_build_info(void);
 /* Diagnostic: resident workgroups (64 voices each) of the tube kernel per CU, per the HIP occupancy query. */
 int  trm_kernel_blocks_per_cu(void);
+/* Same for a given kernel form (TRM_KERNEL_WIDE / TRM_KERNEL_QUAD). */
+int  trm_kernel_blocks_per_cu_form(int kernel);
 
 #ifdef __cplusplus
 }

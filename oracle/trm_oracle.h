@@ -68,6 +68,12 @@ size_t trm_oracle_wav_data(const trm_input_params *params, const double *samples
  * last row doubled). */
 int  trm_oracle_parse_file(const char *path, trm_input_params *params, double **frames, size_t *nframes);
 
+
+/* Control-track generation (oracle/evt_oracle.c): EventList.m:883-1061 + MMDriftGenerator.m. */
+int trm_oracle_count_frames(const uint32_t *times, size_t n, const trm_intonation *s, size_t *nframes);
+int trm_oracle_generate_frames(const uint32_t *times, const double *values, size_t n, const trm_intonation *s,
+                               float *frames_out, size_t frames_cap, size_t *nframes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,9 @@ def lib():
         L.trm_oracle_wav_data.argtypes = [C.POINTER(InputParams), C.POINTER(C.c_double), C.c_int32,
                                           C.c_double, C.POINTER(C.c_uint8), C.c_size_t]
         L.trm_oracle_wav_data.restype = C.c_size_t
+        L.trm_oracle_count_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.trm_oracle_generate_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.POINTER(C.c_size_t)]
         L.trm_oracle_parse_file.argtypes = [C.c_char_p, C.POINTER(InputParams),
                                             C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
         L.trm_oracle_parse_file.restype = C.c_int
@@ -218,3 +221,24 @@ def run_ref(params, frames, workdir):
     r["tubeSamples"] = take(np.float64, ntube).copy()
     r["samples_f32"] = take(np.float32, nout).copy()
     return r
+
+
+class Intonation(C.Structure):
+    """trm_intonation (include/trm_c_api.h)."""
+    _fields_ = [("useMicroIntonation", C.c_int32), ("useMacroIntonation", C.c_int32), ("useSmoothIntonation", C.c_int32),
+                ("useDrift", C.c_int32), ("driftDeviation", C.c_float), ("driftCutoff", C.c_float), ("pitchMean", C.c_double),
+                ("timeQuantization", C.c_uint32), ("startTime_ms", C.c_uint32), ("endTime_ms", C.c_uint32)]
+
+
+def generate_frames(times, values, settings):
+    """EventList.m:883-1061 restated (oracle/evt_oracle.c): (times u32[n], values f64[n,36]) -> frames f32[m,16]."""
+    t = np.ascontiguousarray(times, dtype=np.uint32)
+    v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, 36)
+    s = Intonation.from_buffer_copy(bytes(settings)) if not isinstance(settings, Intonation) else settings
+    n = C.c_size_t()
+    lib().trm_oracle_count_frames(t.ctypes.data, len(t), C.addressof(s), C.byref(n))
+    out = np.zeros((max(n.value, 1), 16), dtype=np.float32)
+    m = C.c_size_t()
+    lib().trm_oracle_generate_frames(t.ctypes.data, v.ctypes.data, len(t), C.addressof(s), out.ctypes.data, n.value, C.byref(m))
+    assert m.value == n.value
+    return out[:m.value]
