@@ -56,7 +56,7 @@ EXPORTS = [
     "trm_strerror", "trm_last_error", "trm_data_list_read_file", "trm_data_list_write_file", "trm_free",
     "trm_tube_create", "trm_tube_destroy", "trm_tube_derived", "trm_tube_synthesize",
     "trm_tube_number_samples", "trm_tube_maximum_sample_value", "trm_tube_samples",
-    "trm_tube_save_output_to_file", "trm_tube_generate_wav_data",
+    "trm_tube_save_output_to_file", "trm_tube_generate_wav_data", "trm_write_sound_file",
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
@@ -126,6 +126,7 @@ def lib():
     L.trm_events_count_frames.argtypes = [vp, C.c_size_t, C.POINTER(TrmIntonation), C.POINTER(C.c_size_t)]
     L.trm_batch_generate_frames_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.POINTER(TrmIntonation), vp, vp, vp, vp]
     L.trm_batch_generate_frames_host.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(TrmIntonation), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.trm_write_sound_file.argtypes = [C.POINTER(TrmInputParams), vp, C.c_size_t, C.c_float, C.c_char_p]
     L.trm_batch_set_kernel.argtypes = [vp, C.c_int]
     L.trm_kernel_blocks_per_cu_form.argtypes = [C.c_int]
     L.trm_batch_last_kernel.argtypes = [vp]

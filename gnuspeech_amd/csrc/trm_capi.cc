@@ -625,6 +625,14 @@ int trm_tube_save_output_to_file(trm_tube *t, const char *filename)
     return TRM_OK;
 }
 
+int trm_write_sound_file(const trm_input_params *params, const float *samples, size_t n, float maximumSampleValue, const char *filename)
+{
+    if (!params || !filename || (n && !samples)) return fail(TRM_EINVAL, "null argument");
+    int rc = trm::io_write_sound_file(filename, *params, samples, n, (double)maximumSampleValue);
+    if (rc) return fail(rc, "cannot write %s", filename);
+    return TRM_OK;
+}
+
 int trm_tube_generate_wav_data(trm_tube *t, uint8_t *buf, size_t cap, size_t *len)
 {
     if (!t || !len) return fail(TRM_EINVAL, "null argument");

@@ -188,6 +188,13 @@ int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,
                                      const uint32_t *d_number_samples, const float *d_max_sample,
                                      int16_t *d_int16, int for_wav_data, void *stream);
 
+/* -saveOutputToFile:error: (TRMTubeModel.m:365-490) for one voice of a batch: writes `n` fp32 samples
+ * with their maximumSampleValue as the AU / AIFF / WAVE file params->outputFileFormat names (int16, the
+ * reference's scale, balance and byte order).  Host-side container code; the samples come from
+ * trm_batch_synthesize_*. */
+int  trm_write_sound_file(const trm_input_params *params, const float *samples, size_t n, float maximumSampleValue,
+                          const char *filename);
+
 /* ---------------------------------------------------------------------------------------------
  * Control-track generation at 250 Hz: the step in front of the tube.
  * Replaces -[EventList generateOutputInTimeRange:forSynthesizer:parameterLogger:]

@@ -199,6 +199,38 @@ def test_synthesizer_facade_and_writers(g, tmp_path):
         assert len(body) == len(ref) and np.max(np.abs(diff)) <= 8
 
 
+def test_cli_batch_directory_equals_single_file_mode(g, tmp_path):
+    """tools/softwaretrm.py --batch: every file of a directory in one launch per parameter set; each output file
+    is byte-identical to what the reference-shaped single-file mode (Frameworks/Tube/main.m:12-67) writes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    indir, out_b, out_s = tmp_path / "in", tmp_path / "batch", tmp_path / "single"
+    os.makedirs(indir)
+    os.makedirs(out_s)
+    rows = cases.load_gnuspeech_rows()
+    names = []
+    for i, (lo, hi, fmt) in enumerate(((0, 40, 2), (50, 75, 2), (100, 160, 2), (10, 30, 0))):
+        dl = g.TRMDataList()
+        pd = cases.monet_default_params(22050.0)
+        pd["outputFileFormat"] = fmt
+        dl.inputParameters = g.TRMInputParameters.from_dict(pd)
+        dl.values = [g.TRMParameters(r) for r in rows[lo:hi]]
+        name = "utt%d.trm" % i
+        dl.writeToFile(str(indir / name))
+        names.append((name, ".wav" if fmt == 2 else ".au"))
+    tool = os.path.join(root, "tools", "softwaretrm.py")
+    r = subprocess.run([sys.executable, tool, "--batch", str(indir), str(out_b)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "4 files in 2 launches" in r.stdout
+    for name, ext in names:
+        single = str(out_s / (name[:-4] + ext))
+        r = subprocess.run([sys.executable, tool, str(indir / name), single], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(single, "rb").read() == open(str(out_b / (name[:-4] + ext)), "rb").read()
+
+
 def test_device_path_and_int16(g, form):
     """Device-buffer entry (what bench.py times) == host-buffer entry; int16 normalisation on device."""
     import torch
