@@ -26,13 +26,14 @@ constexpr int kQB = kSlots;          // tube samples per step = time slots per v
 constexpr int kQRoles = 6;           // osc, mix, coef x2 (area | frication), tube, convert
 constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
 constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
-constexpr int kOStride = kORing + kOMirror + 2;   // + 16 bytes: the 16 voices' rings start in different LDS banks
+constexpr int kOStride = kORing + kOMirror + 4;   // + 32 bytes: a row of lanes (4 voices x 2 distinct window starts) reads 8 different 16-byte bank groups
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
 constexpr int kQBufs = 3;           // mix/coef -> tube hand-off buffers: block b lives in buffer b % 3 (the tube stage reads block
                                      // i-3 and the head of block i-2 while block i-1 is being written)
 constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS: block B in buffer B % 3
+constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes apart, so that 16 lanes reading 16 rows hit 16 bank groups
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
                                      // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
 
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     __shared__ uint4 sInfo[kQV];
     __shared__ float sMx[8 * kWave];
     __shared__ float sNoise[kNoiseRing];
-    __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kSrcRowC];   // mix -> convert: coefficient rows of 3 blocks
+    __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kRowPitch];   // mix -> convert: coefficient rows of 3 blocks
 
     constexpr int kStampRoles = kQRoles;
     (void)kStampRoles;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             if (rowsInFlight) {
-                float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) % kRowBufs) * (kCvtCols * kSrcRowC) + lane * 16]);
+                float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) % kRowBufs) * (kCvtCols * kRowPitch) + (lane >> 1) * kRowPitch + (lane & 1) * 16]);
                 for (int q = 0; q < 4; q++) dst[q] = rq[q];
                 rowsInFlight = false;
             }
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk % kRowBufs) * (kCvtCols * kSrcRowC) + col * kSrcRowC]);
+            const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk % kRowBufs) * (kCvtCols * kRowPitch) + col * kRowPitch]);
             for (int q = 0; q < 8; q++) {
                 const float4 x = row[q];
                 cc[2 * q] = v2f{x.x, x.y};
