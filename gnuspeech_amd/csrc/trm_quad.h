@@ -172,16 +172,30 @@ TRM_HD void quad_reset(QuadState<F> &S)
     S.bx1 = S.bx2 = S.by1 = S.by2 = z;
 }
 
-// One tube sample.  Returns the tube-rate output in PART 2 (other parts: unspecified).
+// The two recurrences that only FEED the tube (nothing of the tube's state enters them), as single
+// evaluations: on the device they run in feed-forward waves, serially over the four time slots of a voice.
+//   frication band-pass (TRMFilters.m:19-29), coefficients doubled (see SharedRecord)
 template <class F>
-TRM_HD F tube_quad_step(QuadState<F> &S, const Const &C, F gin, F sig, F thr, F bpA2, F bpB2, F bpG2,
-                        typename PairOf<F>::type endK, typename PairOf<F>::type endOnePlus, typename PairOf<F>::type kA,
-                        typename PairOf<F>::type kB, typename PairOf<F>::type tA, typename PairOf<F>::type tB)
+TRM_HD F bandpass_eval(F bpA2, F bpB2, F bpG2, F x, F x2, F y1, F y2)
+{
+    return fma_f(bpA2, x - x2, fma_f(bpG2, y1, -(bpB2 * y2)));
+}
+//   throat low-pass (:341, TRMFilters.m:72-77)
+template <class F>
+TRM_HD F throat_eval(const Const &C, F thr, F y1)
+{
+    return F(C.ta0) * thr + F(C.tb1) * y1;
+}
+
+// One tube sample given the band-pass output `fr` and the throat output `ty` of that sample.
+// Returns the tube-rate output in PART 2 (other parts: unspecified).
+template <class F>
+TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F fr, F ty, typename PairOf<F>::type endK,
+                        typename PairOf<F>::type endOnePlus, typename PairOf<F>::type kA, typename PairOf<F>::type kB,
+                        typename PairOf<F>::type tA, typename PairOf<F>::type tB)
 {
     typedef typename PairOf<F>::type P;
     const F d = F(C.damping);
-    const F fr = fma_f(bpA2, sig - S.bx2, fma_f(bpG2, S.by1, -(bpB2 * S.by2)));
-    S.bx2 = S.bx1; S.bx1 = sig; S.by2 = S.by1; S.by1 = fr;
 
     // ---- gather every junction's two inputs from the previous sample's outputs
     F a0 = S.A0;                                   // J1 <- glottis end
@@ -228,11 +242,22 @@ TRM_HD F tube_quad_step(QuadState<F> &S, const Const &C, F gin, F sig, F thr, F 
     P rin = endOnePlus * ei;
     P rad = cf * (rin - S.radX + S.radY);
     S.radX = rin; S.radY = rad;
-    // ---- throat (:341, TRMFilters.m:72-77) and the output sum
-    F ty = F(C.ta0) * thr + F(C.tb1) * S.thY;
-    S.thY = ty;
+    // ---- the output sum (:346): mouth + nose, then the throat
     F out = rad.x + rad.y;
     return ty * F(C.throatGain) + out;
+}
+
+// The whole sample in one call (host model): band-pass and throat state live in S.
+template <class F>
+TRM_HD F tube_quad_step(QuadState<F> &S, const Const &C, F gin, F sig, F thr, F bpA2, F bpB2, F bpG2,
+                        typename PairOf<F>::type endK, typename PairOf<F>::type endOnePlus, typename PairOf<F>::type kA,
+                        typename PairOf<F>::type kB, typename PairOf<F>::type tA, typename PairOf<F>::type tB)
+{
+    const F fr = bandpass_eval(bpA2, bpB2, bpG2, sig, S.bx2, S.by1, S.by2);
+    S.bx2 = S.bx1; S.bx1 = sig; S.by2 = S.by1; S.by1 = fr;
+    const F ty = throat_eval(C, thr, S.thY);
+    S.thY = ty;
+    return tube_quad_core(S, C, gin, fr, ty, endK, endOnePlus, kA, kB, tA, tB);
 }
 
 // ================================================================ oscillator, time-slot form

@@ -10,7 +10,8 @@
 //   convert          lane = output time, as in the wide kernel (rows of 32 outputs x 2 voices)
 // so one pass of the instruction streams advances 4 tube samples and 256 workgroups cover 4096 voices.
 // One barrier per step of kQB = 4 tube samples; osc works on block i, mix and coef on block i-1, tube on
-// block i-3, convert on whatever is complete, metered.
+// block i-4 (the band-pass and throat recurrences, which only FEED the tube, run in the coefficient and mix
+// waves on blocks i-2 and i-1), convert on whatever is complete, metered.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,8 +31,8 @@ constexpr int kOStride = kORing + kOMirror + 4;   // + 32 bytes: a row of lanes 
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
-constexpr int kQBufs = 3;           // mix/coef -> tube hand-off buffers: block b lives in buffer b % 3 (the tube stage reads block
-                                     // i-3 and the head of block i-2 while block i-1 is being written)
+constexpr int kQBufs = 4;           // mix/coef -> tube hand-off buffers: block b lives in buffer b % 4 (the tube stage reads block
+                                     // i-4 and the head of block i-3, the band-pass works on block i-2, block i-1 is being written)
 constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS: block B in buffer B % 3
 constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes apart, so that 16 lanes reading 16 rows hit 16 bank groups
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     // others are paired so that the SIMDs carry about the same work (tools/stage_profile.py)
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifndef TRM_QROLE_PERM
-#define TRM_QROLE_PERM 1, 0, 5, 4, 2, 3      /* mix osc convert tube | coef-area coef-fric */
+#define TRM_QROLE_PERM 5, 1, 0, 4, 2, 3      /* convert mix osc tube | coef-area coef-fric */
 #endif
     const int rolePerm[kQRoles] = {TRM_QROLE_PERM};
     int role = 0;
@@ -76,8 +77,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     const uint32_t inc = C.timeRegisterIncrement;
     const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
-    // the tube stage steps block i-3 at step i; the convert wave finishes what is queued after the last barrier
-    const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 4 : 0;
+    // the tube stage steps block i-4 at step i; the convert wave finishes what is queued after the last barrier
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 5 : 0;
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // and visible one step after that: >= 2 steps before the convert wave can begin the block (it needs the
         // block's predecessor complete: tube time past the block's first output), and buffer B % 3 is rewritten
         // 3 blocks (~43 tube samples, ~11 steps) later, >= 5 steps after the convert wave copied its row.
+        float thY = 0.0f, thNext = 0.0f;      // throat memory as seen by this lane's slot; slot 0's for the next block
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
         float4 rq[4];
@@ -225,7 +227,19 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const float pulse = acc0.x + acc0.y;
                 const float2 a = sA[buf * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
-                sX[(xbuf * kQB + part) * kXPitch + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                // throat low-pass (:341, TRMFilters.m:72-77): nothing of the tube enters it, so it runs here, serially
+                // over the voice's four slots (slot s hands its output to slot s+1, slot 3 to the next block's slot 0)
+                float ty = 0.0f;
+#pragma unroll
+                for (int t = 0; t < kQB; t++) {      // a lane's value is final from its own turn on: its input no longer changes
+                    ty = throat_eval<float>(C, E.thr, thY);
+                    if (t == 0) thY = q_take<1, kPart1>(thY, ty);
+                    if (t == 1) thY = q_take<1, kPart2>(thY, ty);
+                    if (t == 2) thY = q_take<1, kPart3>(thY, ty);
+                    if (t == 3) thNext = q_take<1, kPart0>(thNext, ty);
+                }
+                thY = q_take<0, kPart0>(thY, thNext);
+                sX[(xbuf * kQB + part) * kXPitch + vq] = make_float4(E.gin, E.sig, ty, 0.0f);
             }
             STAMP_MID
             step_barrier();
@@ -238,6 +252,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // Two waves share the stage by FUNCTION (both are stateless in time): role 2 turns radii and velum into
         // scattering coefficients, role 3 turns the frication tracks into taps and the band-pass.
         const bool area = role == 2;
+        // (area wave) frication band-pass memory as seen by this lane's slot, and what slots 0 / 1 start the
+        // next block with
+        float by1 = 0.0f, by2 = 0.0f, ny1 = 0.0f, ny2 = 0.0f, prevSig = 0.0f;
         CoefTrack T;
         float prev[16], cur[16], nxt[16];
         uint32_t per = 0, j = (uint32_t)part;
@@ -282,24 +299,49 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 }
                 j += kQB;
             }
+            if (area && step >= 2 && (step - 2) * kQB < nTotal) {
+                // Frication band-pass (TRMFilters.m:19-29) of block i-2: its input (mix, step i-1) and its
+                // coefficients (the other coefficient wave, step i-1) are in LDS; nothing of the tube enters it.
+                // Serial over the voice's four slots: slot s's output is slot s+1's y1 and slot s+2's y2; what
+                // wraps around belongs to the next block.  A lane's evaluation is final from its own turn on
+                // (its inputs no longer change), so the value of the last turn is everyone's.
+                const int b2 = (step - 2) % kQBufs;
+                float *const xr = reinterpret_cast<float *>(&sX[(b2 * kQB + part) * kXPitch + vq]);
+                const float sig = xr[1];
+                const float4 bp = sBP[((b2 * 2) * kQB + part) * kXPitch + vq];
+                const float X = q_take<0, kPart2 | kPart3>(sig, prevSig);       // slots 0, 1 look into the previous block
+                const float x2 = q_take<2, kPartAll>(X, X);
+                float f = 0.0f;
+#pragma unroll
+                for (int t = 0; t < kQB; t++) {
+                    f = bandpass_eval<float>(bp.x, bp.y, bp.z, sig, x2, by1, by2);
+                    if (t == 0) { by1 = q_take<1, kPart1>(by1, f); by2 = q_take<2, kPart2>(by2, f); }
+                    if (t == 1) { by1 = q_take<1, kPart2>(by1, f); by2 = q_take<2, kPart3>(by2, f); }
+                    if (t == 2) { by1 = q_take<1, kPart3>(by1, f); ny2 = q_take<2, kPart0>(ny2, f); }
+                    if (t == 3) { ny1 = q_take<1, kPart0>(ny1, f); ny2 = q_take<2, kPart1>(ny2, f); }
+                }
+                by1 = q_take<0, kPart0>(by1, ny1);
+                by2 = q_take<0, kPart0 | kPart1>(by2, ny2);
+                prevSig = sig;
+                xr[1] = f;
+            }
             STAMP_MID
             step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
     } else if (role == 4) {
-        // ------------------------------------------------------------ tube: block i-2 at step i, lane = (voice, part)
+        // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
         QuadState<float> S;
         quad_reset(S);
         float4 *const ring = reinterpret_cast<float4 *>(&sY[vq * kYStride]);
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
-        // one sample's inputs: {gin, sig, thr}, band-pass, end coefficients, this part's record
-        struct In { float4 x, bp, e4, k4, t4; };
+        // one sample's inputs: {gin, band-pass output, throat output}, end coefficients, this part's record
+        struct In { float4 x, e4, k4, t4; };
         auto load_in = [&](uint32_t blk, int s) {
             const int buf = blk % kQBufs;
             In r;
             r.x = sX[(buf * kQB + s) * kXPitch + vq];
-            r.bp = sBP[((buf * 2) * kQB + s) * kXPitch + vq];
             r.e4 = sBP[((buf * 2 + 1) * kQB + s) * kXPitch + vq];
             const float4 *rec = &sK[(buf * kQB + s) * kKPitch + lane];
             r.k4 = rec[0];
@@ -307,20 +349,20 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             return r;
         };
         auto step_one = [&](const In &r) {
-            return tube_quad_step<float>(S, C, r.x.x, r.x.y, r.x.z, r.bp.x, r.bp.y, r.bp.z, v2f_t{r.e4.x, r.e4.y},
-                                         v2f_t{r.e4.z, r.e4.w}, v2f_t{r.k4.x, r.k4.y}, v2f_t{r.k4.z, r.k4.w},
-                                         v2f_t{r.t4.x, r.t4.y}, v2f_t{r.t4.z, r.t4.w});
+            return tube_quad_core<float>(S, C, r.x.x, r.x.y, r.x.z, v2f_t{r.e4.x, r.e4.y}, v2f_t{r.e4.z, r.e4.w},
+                                         v2f_t{r.k4.x, r.k4.y}, v2f_t{r.k4.z, r.k4.w}, v2f_t{r.t4.x, r.t4.y},
+                                         v2f_t{r.t4.z, r.t4.w});
         };
-        // Block i-3 at step i.  Its first sample's inputs were fetched during step i-1 (block i-3 was complete
-        // by then), the other three are fetched now and land behind the first sample's arithmetic, and the
-        // head of block i-2 is fetched behind the last: no LDS latency is exposed.
+        // Block i-4 at step i (its band-pass output was written during step i-2).  Its first sample's inputs were
+        // fetched during step i-1, the other three are fetched now and land behind the first sample's
+        // arithmetic, and the head of block i-3 is fetched behind the last: no LDS latency is exposed.
         In head;
-        head.x = head.bp = head.e4 = head.k4 = head.t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        head.x = head.e4 = head.k4 = head.t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 3 && (step - 3) * kQB < nTotal) {
-                const uint32_t blk = step - 3;
+            if (step >= 4 && (step - 4) * kQB < nTotal) {
+                const uint32_t blk = step - 4;
                 const uint32_t n0 = blk * kQB;
                 const In i1 = load_in(blk, 1), i2 = load_in(blk, 2), i3 = load_in(blk, 3);
                 float y[kQB];
@@ -346,7 +388,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                             if (n0 + s < lim) tubeOut[n0 + s] = y[s];
                     }
                 }
-            } else if (step == 2 && nTotal > 0) {
+            } else if (step == 3 && nTotal > 0) {
                 head = load_in(0, 0);
             }
             STAMP_MID
@@ -444,8 +486,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            // visible after the previous barrier: tube samples n < (step-3)*kQB
-            const uint32_t ready = step >= 3 ? (step - 3) * kQB : 0;
+            // visible after the previous barrier: tube samples n < (step-4)*kQB
+            const uint32_t ready = step >= 4 ? (step - 4) * kQB : 0;
             credit += earn;
             if (credit > (2u << 16)) credit = 2u << 16;   // at most two pairs per step: a ready block is spread over the next steps, not done in a burst
             if (needBegin && step >= 2) { begin_block(); needBegin = false; }
