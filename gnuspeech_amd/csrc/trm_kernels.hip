@@ -332,6 +332,10 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         // a little more than the kTB tube samples of a step turn into (pairs of this wave per step =
         // kTB * 2^16/inc / 4), and a pair runs when a whole one has been earned and its block is readable.
         const uint32_t earn = (uint32_t)(((uint64_t)kTB << 32) / inc / 4) + 2048;
+        // the cap must leave room to catch up after waiting for a block (a cap of about `earn` loses credit while
+        // it waits and the wave falls behind until the ring laps it: seen at a 30 cm tube, ratio 3.8)
+        const uint32_t capPairs = (earn + 0x18000u) >> 16;                  // floor(earn + 1.5)
+        const uint32_t creditCap = (capPairs > 2u ? capPairs : 2u) << 16;   // two pairs per step at speech rates (earn ~ 1.1)
         uint32_t credit = 0;
         SUB_DECL
         auto do_pair = [&]() {
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             // visible after the previous barrier: tube samples n < (step-2)*kTB
             const uint32_t ready = step >= 2 ? (step - 2) * kTB : 0;
             credit += earn;
-            if (credit > (2u << 16)) credit = 2u << 16;   // at most two pairs per step: a ready block is spread over the next steps, not done in a burst
+            if (credit > creditCap) credit = creditCap;     // a ready block is spread over the next steps, not done in a burst
             while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {
                 credit -= 1u << 16;
                 do_pair();

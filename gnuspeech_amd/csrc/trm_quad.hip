@@ -47,6 +47,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     __shared__ __attribute__((aligned(16))) float4 sK[kQBufs * kQB * kKPitch];     // coef -> tube: part records
     __shared__ __attribute__((aligned(16))) float sY[kQV * kYStride];             // tube-rate rings
     __shared__ uint4 sInfo[kQV];
+    __shared__ uint32_t sRowSync[2];     // [0] convert -> mix: first block whose staged rows are still needed; [1] mix -> convert: blocks staged
     __shared__ float sMx[8 * kWave];
     __shared__ float sNoise[kNoiseRing];
     __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kRowPitch];   // mix -> convert: coefficient rows of 3 blocks
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
 
     for (int i = threadIdx.x; i < kQV * kYStride; i += kWave * kQRoles) sY[i] = 0.0f;
     for (int i = threadIdx.x; i < kQV * kOStride; i += kWave * kQRoles) sO[i] = make_float2(0.0f, 0.0f);
+    if (threadIdx.x < 2) sRowSync[threadIdx.x] = 0u;
     __syncthreads();
 
 #ifdef TRM_ABL_SKIP      // timing experiments only (tools/bench_variants.sh): the masked roles keep the barriers and do nothing
@@ -171,11 +173,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         }
         const float2 *const ring = &sO[vq * kOStride];
         // Converter coefficient rows, staged for the convert wave: block B's 32 rows (128 bytes each, shifted per
-        // output like the wide kernel's fetch) are loaded when the oscillator (4 tube samples per step, 3 steps
-        // ahead of the tube stage) is within 4 samples of the block's first output, written to LDS one step later
-        // and visible one step after that: >= 2 steps before the convert wave can begin the block (it needs the
-        // block's predecessor complete: tube time past the block's first output), and buffer B % 3 is rewritten
-        // 3 blocks (~43 tube samples, ~11 steps) later, >= 5 steps after the convert wave copied its row.
+        // output like the wide kernel's fetch) are loaded when the oscillator's time is within 4 samples of the
+        // block's first output, written to LDS one step later and visible one step after that -- normally several
+        // steps before the convert wave can begin the block.  Two words in LDS make that independent of timing:
+        // sRowSync[1] = blocks staged (the convert wave begins no block beyond it), sRowSync[0] = the first block
+        // whose rows the convert wave has not copied yet (buffer B % 3 is not rewritten before).
         float thY = 0.0f, thNext = 0.0f;      // throat memory as seen by this lane's slot; slot 0's for the next block
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
@@ -188,8 +190,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) % kRowBufs) * (kCvtCols * kRowPitch) + (lane >> 1) * kRowPitch + (lane & 1) * 16]);
                 for (int q = 0; q < 4; q++) dst[q] = rq[q];
                 rowsInFlight = false;
+                if (lane == 0) sRowSync[1] = rowBlk;            // blocks 0 .. rowBlk-1 are in LDS after this step's barrier
             }
-            if (rowBlk < cvtBlocks && src_position(rowBlk * kCvtCols, inc) <= step * kQB + 4u) {
+            // never more than kRowBufs blocks past the first one the convert wave still has to copy (looked up only
+            // when a block is due: once per block)
+            if (rowBlk < cvtBlocks && src_position(rowBlk * kCvtCols, inc) <= step * kQB + 4u &&
+                rowBlk < __builtin_amdgcn_readfirstlane(sRowSync[0]) + kRowBufs) {
                 const uint32_t k = rowBlk * kCvtCols + ((uint32_t)lane >> 1);
                 const uint32_t off = (src_position(k, inc) + (kQLead - (kSrcWindow - 1))) & 3u;
                 const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off + (lane & 1) * 16;
@@ -433,12 +439,24 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 cc[2 * q + 1] = v2f{x.z, x.w};
             }
         };
-        bool needBegin = nBlocks > 0;   // block 0's rows are visible from step 2 on
+        auto begin_block_from_global = [&]() {
+            kLane = blk * kCvtCols + col;
+            winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
+            needLast = nTotal - 1;
+            const uint32_t off = (src_position(kLane, inc) + kRingShift) & 3u;
+            const float *pc = A.src_rows + (size_t)src_phase(kLane, inc) * kSrcRowC - off;
+            for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
+        };
+        bool needBegin = nBlocks > 0;
         typedef __attribute__((address_space(1))) float *GlobalFloatPtr;
         typedef __attribute__((address_space(3))) float *LdsFloatPtr;
         // metering (16.16 row pairs per step): a step's kQB tube samples turn into kQB * 2^16/inc outputs per
         // voice = that / 32 blocks of 4 row pairs
         const uint32_t earn = (uint32_t)(((uint64_t)kQB << 32) / inc / 8) + 2048;
+        // the cap must leave room to catch up after waiting for a block (a cap of about `earn` loses credit while
+        // it waits and the wave falls behind until the ring laps it: seen at a 30 cm tube, ratio 3.8)
+        const uint32_t capPairs = (earn + 0x18000u) >> 16;                  // floor(earn + 1.5)
+        const uint32_t creditCap = (capPairs > 2u ? capPairs : 2u) << 16;   // two pairs per step at speech rates (earn ~ 1.1)
         uint32_t credit = 0;
         auto do_pair = [&]() {
             const int la = 4 * (int)pr, lb = la + 2;
@@ -489,21 +507,36 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             // visible after the previous barrier: tube samples n < (step-4)*kQB
             const uint32_t ready = step >= 4 ? (step - 4) * kQB : 0;
             credit += earn;
-            if (credit > (2u << 16)) credit = 2u << 16;   // at most two pairs per step: a ready block is spread over the next steps, not done in a burst
-            if (needBegin && step >= 2) { begin_block(); needBegin = false; }
+            if (credit > creditCap) credit = creditCap;     // a ready block is spread over the next steps, not done in a burst
+            // (the two sync words are touched once per block: when a block has to begin)
+            auto try_begin = [&]() {
+                if (blk < __builtin_amdgcn_readfirstlane(sRowSync[1])) {
+                    begin_block();
+                    needBegin = false;
+                    if (lane == 0) sRowSync[0] = blk + 1;       // this block's rows are in registers now
+                }
+            };
+            if (needBegin) try_begin();
             while (credit >= (1u << 16) && blk < nBlocks && !needBegin && needLast < ready) {
                 credit -= 1u << 16;
                 do_pair();
-                if (needBegin) { begin_block(); needBegin = false; }     // the next block's rows were staged steps ago
+                if (needBegin) try_begin();
             }
             STAMP_MID
             step_barrier();
             STAMP_END
         }
         STAMP_STORE(role)
-        while (blk < nBlocks) {
-            if (needBegin) { begin_block(); needBegin = false; }
-            do_pair();
+        {   // after the last barrier: what is staged is final; a block beyond it fetches its row itself
+            const uint32_t staged = __builtin_amdgcn_readfirstlane(sRowSync[1]);
+            while (blk < nBlocks) {
+                if (needBegin) {
+                    if (blk < staged) begin_block();
+                    else begin_block_from_global();
+                    needBegin = false;
+                }
+                do_pair();
+            }
         }
         float myMax = 0.0f;     // collected by lanes 0..15: voice `lane` of the workgroup
 #pragma unroll

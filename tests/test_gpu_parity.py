@@ -127,6 +127,17 @@ def test_downsampling_batch(g, form):
     _batch_vs_oracle(g, pd, voices)
 
 
+def test_extreme_rate_ratios(g, form):
+    """Converter ratios at both ends of the up-sampling range: a 30 cm tube (tube rate ~11.7 kHz, ratio 3.8 at
+    44.1 kHz: the converter produces ~15 outputs per pipeline step) and a 15.8 cm tube at 22.05 kHz (ratio 1.008)."""
+    rows = cases.load_gnuspeech_rows()
+    for length, rate in ((30.0, 44100.0), (15.8, 22050.0)):
+        pd = cases.monet_default_params(rate)
+        pd["length"] = length
+        voices = [rows[i:i + 40].copy() for i in range(0, 200, 11)]
+        _batch_vs_oracle(g, pd, voices)
+
+
 def test_tract_defaults_and_sine(g, form):
     rows = cases.load_gnuspeech_rows()
     _batch_vs_oracle(g, cases.tract_default_params(), [cases.static_frames(cases.TRACT_VOWEL_FRAME, 21)])
