@@ -138,6 +138,17 @@ def test_extreme_rate_ratios(g, form):
         _batch_vs_oracle(g, pd, voices)
 
 
+def test_short_control_periods(g, form):
+    """Control rates far above Monet's 250 Hz: control periods of 10 and 5 tube samples (the pipelines step 2 or 4
+    tube samples at a time, so a period boundary falls inside almost every step)."""
+    rows = cases.load_gnuspeech_rows()
+    for rate in (2000.0, 4000.0):
+        pd = cases.monet_default_params(44100.0)
+        pd["controlRate"] = rate
+        voices = [rows[i:i + 120].copy() for i in range(0, 150, 7)] + [rows[3:5].copy(), np.zeros((0, 16))]
+        _batch_vs_oracle(g, pd, voices)
+
+
 def test_tract_defaults_and_sine(g, form):
     rows = cases.load_gnuspeech_rows()
     _batch_vs_oracle(g, cases.tract_default_params(), [cases.static_frames(cases.TRACT_VOWEL_FRAME, 21)])
