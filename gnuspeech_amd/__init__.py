@@ -4,6 +4,7 @@ host-side mirror of the reference's Tube framework interface plus a batch front 
 from ._capi import LIB_PATH, TrmError, lib  # noqa: F401
 from .batch import TRMBatch  # noqa: F401
 from .events import Event, EventList, MMIntonation, intonation_struct  # noqa: F401
+from .stream import TRMStream  # noqa: F401
 from .tube import (TRMDataList, TRMInputParameters, TRMParameters, TRMSynthesizer, TRMTubeModel,  # noqa: F401
                    TRMSoundFileFormat_AIFF, TRMSoundFileFormat_AU, TRMSoundFileFormat_WAVE,
                    TRMWaveFormType_Pulse, TRMWaveFormType_Sine)

@@ -60,6 +60,8 @@ EXPORTS = [
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
+    "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
+    "trm_stream_push", "trm_stream_finish",
     "trm_events_count_frames", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
     "trm_batch_set_kernel", "trm_batch_last_kernel",
     "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
@@ -123,6 +125,14 @@ def lib():
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]
     L.trm_batch_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.trm_stream_create.argtypes = [C.POINTER(TrmInputParams), C.c_int, C.c_size_t, C.POINTER(vp)]
+    L.trm_stream_destroy.argtypes = [vp]
+    L.trm_stream_samples_for_push.argtypes = [vp, C.c_size_t]
+    L.trm_stream_samples_for_push.restype = C.c_size_t
+    L.trm_stream_samples_for_finish.argtypes = [vp]
+    L.trm_stream_samples_for_finish.restype = C.c_size_t
+    L.trm_stream_push.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_uint32), vp]
+    L.trm_stream_finish.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), vp]
     L.trm_events_count_frames.argtypes = [vp, C.c_size_t, C.POINTER(TrmIntonation), C.POINTER(C.c_size_t)]
     L.trm_batch_generate_frames_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.POINTER(TrmIntonation), vp, vp, vp, vp]
     L.trm_batch_generate_frames_host.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(TrmIntonation), vp, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -300,6 +300,8 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     a.nvoices = (uint32_t)nvoices;
     a.stamps = nullptr;
     a.sink = b->dRowsAlloc;
+    a.stream_state = nullptr;
+    a.stream_flags = a.stream_n_base = a.stream_k_base = a.stream_k_end = 0;
     a.tube_out = nullptr;
     a.tube_offset = nullptr;
     if (!b->c.upsample) {
@@ -360,6 +362,176 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         HIP_TRY(hipEventRecord(e1, stream));
         b->events.emplace_back(e0, e1);
     }
+    return TRM_OK;
+}
+
+// ------------------------------------------------------------------ streaming synthesis
+struct trm_stream {
+    trm_batch *b = nullptr;
+    size_t nvoices = 0;
+    DevBuf<float> dState, dFrames, dOut, dMax;
+    DevBuf<uint64_t> dFrameOff, dOutOff;
+    DevBuf<uint32_t> dNFrames, dNSamples;
+    std::vector<float> lastFrame;     // [nvoices][16]: the frame the next control period starts from
+    std::vector<float> hostFrames, hostOut;
+    bool haveLast = false;            // an utterance is open
+    bool first = true;                // no chunk of it has been synthesized yet
+    uint64_t nBase = 0, kBase = 0;    // tube samples synthesized / converter outputs emitted so far
+};
+
+int trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out)
+{
+    if (!params || !out || nvoices == 0) return fail(TRM_EINVAL, "null argument / no voices");
+    *out = nullptr;
+    trm_batch *b = nullptr;
+    int rc = trm_batch_create(params, device, &b);
+    if (rc) return rc;
+    if (!b->c.upsample) {
+        trm_batch_destroy(b);
+        return fail(TRM_ERANGE, "streaming carries up-sampling voices only (tube rate %d Hz above the output rate)", b->d.sampleRate);
+    }
+    trm_stream *s = new (std::nothrow) trm_stream();
+    if (!s) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_stream"); }
+    s->b = b;
+    s->nvoices = nvoices;
+    s->lastFrame.assign(nvoices * 16, 0.0f);
+    if ((rc = s->dState.reserve(nvoices * trm::kStreamFloats)) || (rc = s->dFrameOff.reserve(nvoices)) || (rc = s->dOutOff.reserve(nvoices)) ||
+        (rc = s->dNFrames.reserve(nvoices)) || (rc = s->dNSamples.reserve(nvoices)) || (rc = s->dMax.reserve(nvoices))) {
+        trm_stream_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return TRM_OK;
+}
+
+void trm_stream_destroy(trm_stream *s)
+{
+    if (!s) return;
+    if (s->b) (void)hipSetDevice(s->b->device);
+    trm_batch *b = s->b;
+    delete s;               // device buffers first (the batch owns the stream they were used on)
+    trm_batch_destroy(b);
+}
+
+// converter outputs k with read position e_k = (k * inc) >> 16 <= lastSample, i.e. k < result
+static uint64_t outputs_through(uint64_t lastSamplePlusOne, uint32_t inc)
+{
+    if (lastSamplePlusOne == 0) return 0;
+    return ((lastSamplePlusOne << 16) - 1) / inc + 1;
+}
+
+size_t trm_stream_samples_for_push(const trm_stream *s, size_t nframes)
+{
+    if (!s || nframes == 0) return 0;
+    const uint64_t periods = s->haveLast ? nframes : nframes - 1;
+    const uint64_t N = periods * (uint64_t)s->b->d.controlPeriod;
+    return (size_t)(outputs_through(s->nBase + N, s->b->c.timeRegisterIncrement) - s->kBase);
+}
+
+size_t trm_stream_samples_for_finish(const trm_stream *s)
+{
+    if (!s || !s->haveLast) return 0;
+    const uint64_t total = s->nBase + 2ull * (uint64_t)s->b->d.padSize;
+    const uint32_t inc = s->b->c.timeRegisterIncrement;
+    return (size_t)((total * 65536ull + inc - 1) / inc - s->kBase);
+}
+
+// one chunk: `periods` control periods from s->lastFrame through `frames` (nframes rows per voice), or the flush
+static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool flush, float *out, size_t out_pitch,
+                        uint32_t *nout, float *max_out)
+{
+    trm_batch *b = s->b;
+    const size_t V = s->nvoices;
+    const uint32_t CP = (uint32_t)b->d.controlPeriod, inc = b->c.timeRegisterIncrement;
+    const size_t rows = (flush ? 0 : nframes) + (s->haveLast ? 1 : 0);        // frame rows per voice on the device
+    if (rows == 0) { if (nout) *nout = 0; return TRM_OK; }
+    const uint64_t N = (uint64_t)(rows - 1) * CP;
+    const uint64_t kEnd = flush ? ((s->nBase + 2ull * (uint64_t)b->d.padSize) * 65536ull + inc - 1) / inc
+                                : outputs_through(s->nBase + N, inc);
+    const uint64_t count = kEnd - s->kBase;
+    if (nout) *nout = (uint32_t)count;
+    if (s->nBase + N + 2ull * (uint64_t)b->d.padSize + 512 > 0x7FFFFFFFull || kEnd > 0xFFFFFFFFull)
+        return fail(TRM_ERANGE, "stream too long");
+    if (count > 0 && (!out || out_pitch < count)) return fail(TRM_EINVAL, "output pitch %zu < %llu samples", out_pitch, (unsigned long long)count);
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = b->stream;
+    int rc;
+    if ((rc = s->dFrames.reserve(V * rows * 16)) || (rc = s->dOut.reserve(V * (size_t)count + 64))) return rc;
+    s->hostFrames.resize(V * rows * 16);
+    std::vector<uint64_t> foff(V), ooff(V);
+    std::vector<uint32_t> nfr(V, (uint32_t)rows);
+    for (size_t v = 0; v < V; v++) {
+        float *dst = &s->hostFrames[v * rows * 16];
+        size_t r = 0;
+        if (s->haveLast) { memcpy(dst, &s->lastFrame[v * 16], 16 * sizeof(float)); r = 1; }
+        if (!flush) memcpy(dst + r * 16, frames + v * nframes * 16, nframes * 16 * sizeof(float));
+        foff[v] = v * rows;
+        ooff[v] = v * count;
+    }
+    HIP_TRY(hipMemcpyAsync(s->dFrames.p, s->hostFrames.data(), s->hostFrames.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dFrameOff.p, foff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dOutOff.p, ooff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->dNFrames.p, nfr.data(), V * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if ((rc = ensure_noise(b, (uint32_t)(s->nBase + N) + 2u * (uint32_t)b->d.padSize + 256u, st))) return rc;
+    if (N > 0 || flush) {
+        trm::TubeArgs a;
+        a.frames = s->dFrames.p;
+        a.frame_offset = s->dFrameOff.p;
+        a.nframes = s->dNFrames.p;
+        a.out = s->dOut.p;
+        a.out_offset = s->dOutOff.p;
+        a.number_samples = s->dNSamples.p;
+        a.max_sample = s->dMax.p;
+        a.lp_noise = b->dNoise.p + s->nBase;         // the voice-independent noise sequence continues where it stopped
+        a.src_rows = b->dRows;
+        a.sine = b->dSine;
+        a.tube_out = nullptr;
+        a.tube_offset = nullptr;
+        a.nvoices = (uint32_t)V;
+        a.stamps = nullptr;
+        a.sink = b->dRowsAlloc;
+        a.stream_state = s->dState.p;
+        a.stream_flags = (s->first ? 1u : 0u) | (flush ? 2u : 0u);
+        a.stream_n_base = (uint32_t)s->nBase;
+        a.stream_k_base = (uint32_t)s->kBase;
+        a.stream_k_end = (uint32_t)kEnd;
+        HIP_TRY(trm::launch_tube_quad(b->c, a, st));
+        s->first = false;
+    }
+    if (count > 0) {
+        s->hostOut.resize(V * (size_t)count);
+        HIP_TRY(hipMemcpyAsync(s->hostOut.data(), s->dOut.p, V * (size_t)count * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    std::vector<float> mx(V, 0.0f);
+    if (N > 0 || flush) HIP_TRY(hipMemcpyAsync(mx.data(), s->dMax.p, V * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t v = 0; v < V && count > 0; v++) memcpy(out + v * out_pitch, &s->hostOut[v * (size_t)count], (size_t)count * sizeof(float));
+    if (max_out) memcpy(max_out, mx.data(), V * sizeof(float));
+    s->nBase += N;
+    s->kBase = kEnd;
+    return TRM_OK;
+}
+
+int trm_stream_push(trm_stream *s, const float *frames, size_t nframes, float *out, size_t out_pitch, uint32_t *nout, float *max_out)
+{
+    if (!s || !frames || nframes == 0) return fail(TRM_EINVAL, "null argument / no frames");
+    int rc = stream_chunk(s, frames, nframes, false, out, out_pitch, nout, max_out);
+    if (rc) return rc;
+    for (size_t v = 0; v < s->nvoices; v++) memcpy(&s->lastFrame[v * 16], frames + (v * nframes + nframes - 1) * 16, 16 * sizeof(float));
+    s->haveLast = true;
+    return TRM_OK;
+}
+
+int trm_stream_finish(trm_stream *s, float *out, size_t out_pitch, uint32_t *nout, float *max_out)
+{
+    if (!s) return fail(TRM_EINVAL, "null stream");
+    if (!s->haveLast) { if (nout) *nout = 0; return TRM_OK; }
+    int rc = stream_chunk(s, nullptr, 0, true, out, out_pitch, nout, max_out);
+    if (rc) return rc;
+    s->haveLast = false;          // the next push opens a new utterance: tube at rest, converter pre-roll
+    s->first = true;
+    s->nBase = 0;
+    s->kBase = 0;
     return TRM_OK;
 }
 

@@ -33,7 +33,15 @@ struct TubeArgs {
     const uint64_t *tube_offset;
     uint32_t nvoices;
     unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product
-    float *sink;                  // 64 floats nobody reads: where masked converter lanes of trm_tube_kernel_q store
+    float *sink;                  // (unused)
+    // Streaming (trm_tube_kernel_q only): a chunk of a longer utterance.  Null for one-shot synthesis.
+    //   stream_state   kStreamFloats floats per voice, carried from one chunk to the next
+    //   stream_flags   bit 0: first chunk (state ignored: the tube starts at rest, the converter with its 25 zeros
+    //                  of pre-roll); bit 1: last chunk (the converter's 2*pad zeros of flush are appended)
+    //   stream_n_base  tube samples synthesized before this chunk; stream_k_base / stream_k_end: the chunk emits
+    //                  converter outputs k_base <= k < k_end (global indices).  Same for every voice of the launch.
+    float *stream_state;
+    uint32_t stream_flags, stream_n_base, stream_k_base, stream_k_end;
 };
 
 struct ScaleArgs {
@@ -52,6 +60,7 @@ int tube_kernel_blocks_per_cu();
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
 // small-batch form (trm_quad.hip): 16 voices per workgroup, four lanes per voice
+constexpr int kStreamFloats = 192;   // oscillator position, filter memories, 32 samples of FIR / converter history, 4 x 20 tube values
 hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream);
 int tube_quad_kernel_blocks_per_cu();
 // Down-sampling converter (TRMSampleRateConverter.m:234-297) over tube-rate samples in HBM.

@@ -38,6 +38,9 @@ constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes a
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
                                      // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
 
+// kStream: the launch is a chunk of a streamed utterance (state restored / saved); a compile-time switch so that
+// the one-shot instance carries none of it.
+template <bool kStream>
 __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const C, const TubeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float2 sO[kQV * kOStride];            // osc -> mix: oscillator reads
@@ -77,7 +80,13 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     const uint32_t CP = (uint32_t)C.controlPeriod;
     const uint32_t inc = C.timeRegisterIncrement;
     const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
-    const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
+    // streaming: this launch is one chunk of a longer utterance (trm_kernels.h); one-shot = first and last at once
+    constexpr bool streaming = kStream;
+    const bool sFirst = !streaming || (A.stream_flags & 1u), sLast = !streaming || (A.stream_flags & 2u);
+    const uint32_t nBase = streaming ? A.stream_n_base : 0u, kBase = streaming ? A.stream_k_base : 0u;
+    float *const st = streaming ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
+    // tube samples the tube stage produces: the utterance (chunk), then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93)
+    const uint32_t nTotal = nfrMax > 0 ? ntubeMax + (sLast ? 2u * (uint32_t)C.padSize : 0u) : 0;
     // the tube stage steps block i-4 at step i; the convert wave finishes what is queued after the last barrier
     const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 5 : 0;
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
@@ -88,6 +97,19 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     for (int i = threadIdx.x; i < kQV * kYStride; i += kWave * kQRoles) sY[i] = 0.0f;
     for (int i = threadIdx.x; i < kQV * kOStride; i += kWave * kQRoles) sO[i] = make_float2(0.0f, 0.0f);
     if (threadIdx.x < 2) sRowSync[threadIdx.x] = 0u;
+    if (streaming && !sFirst) {
+        // the last 32 tube samples of the previous chunk: positions -32 .. -1 of this chunk's rings
+        __syncthreads();
+        for (int i = threadIdx.x; i < kQV * 32; i += kWave * kQRoles) {
+            const int q = i >> 5, t = i & 31;
+            const uint32_t vv = blockIdx.x * kQV + q < A.nvoices ? blockIdx.x * kQV + q : A.nvoices - 1;
+            const float *h = A.stream_state + (size_t)vv * kStreamFloats;
+            sO[q * kOStride + 32 + t] = make_float2(h[8 + 2 * t], h[9 + 2 * t]);            // slot (-32 + t) & 63
+            const uint32_t slot = (uint32_t)(t - 32 + kQLead) & (kYRing - 1);
+            sY[q * kYStride + slot] = h[72 + t];
+            if (slot < (uint32_t)kYMirror) sY[q * kYStride + slot + kYRing] = h[72 + t];
+        }
+    }
     __syncthreads();
 
 #ifdef TRM_ABL_SKIP      // timing experiments only (tools/bench_variants.sh): the masked roles keep the barriers and do nothing
@@ -101,6 +123,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         auto sine = [&](int i) { return sine_table(i); };
         OscSlotTrack T;
         double P = 0.0;                                 // oscillator position at the start of the block
+        if (streaming && !sFirst) P = *reinterpret_cast<const double *>(st);
         float prev[4], cur[4], nxt[4];
         uint32_t per = 0, j = (uint32_t)part;           // control period / position in it of this lane's sample
         if (nSteps > 0) {
@@ -135,6 +158,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 pre += q_take<2, kPart2 | kPart3>(0.0, pre);
                 const double end = P + pre;
                 const double pos2 = osc_wrap(end), pos1 = osc_wrap(end - oinc);
+                if (streaming && step * kQB + (uint32_t)part + 1u == ntubeLane) *reinterpret_cast<double *>(st) = pos2;   // the chunk's last sample
                 double tot = pre;                                // slot 3's prefix = the block's advance
                 tot = q_take<1, kPart0>(tot, pre);
                 tot = q_take<2, kPart1>(tot, pre);
@@ -155,6 +179,14 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             STAMP_END
         }
         STAMP_STORE(role)
+        if (streaming && laneValid) {
+            // the chunk's last 32 oscillator reads (positions N-32 .. N-1; older than the chunk: still in the ring)
+            for (int t = part; t < 32; t += 4) {
+                const float2 x = ring[(ntubeLane - 32u + (uint32_t)t) & (kORing - 1)];
+                st[8 + 2 * t] = x.x;
+                st[9 + 2 * t] = x.y;
+            }
+        }
     } else if (role == 1) {
         // ------------------------------------------------------------ mix: block i-1 at step i, lane = (voice, slot)
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
@@ -179,10 +211,13 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // sRowSync[1] = blocks staged (the convert wave begins no block beyond it), sRowSync[0] = the first block
         // whose rows the convert wave has not copied yet (buffer B % 3 is not rewritten before).
         float thY = 0.0f, thNext = 0.0f;      // throat memory as seen by this lane's slot; slot 0's for the next block
+        if (streaming && !sFirst) thY = st[2];
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
         float4 rq[4];
-        const uint32_t cvtBlocks = C.upsample ? (wave_max_u32(laneValid && nfr > 0 ? (uint32_t)((((uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc) : 0u) + kCvtCols - 1) / kCvtCols : 0;
+        const uint32_t cvtOutputs = streaming ? A.stream_k_end - kBase
+                                              : wave_max_u32(laneValid && nfr > 0 ? (uint32_t)((((uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc) : 0u);
+        const uint32_t cvtBlocks = C.upsample ? (cvtOutputs + kCvtCols - 1) / kCvtCols : 0;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
@@ -194,10 +229,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             }
             // never more than kRowBufs blocks past the first one the convert wave still has to copy (looked up only
             // when a block is due: once per block)
-            if (rowBlk < cvtBlocks && src_position(rowBlk * kCvtCols, inc) <= step * kQB + 4u &&
+            if (rowBlk < cvtBlocks && src_position(kBase + rowBlk * kCvtCols, inc) - nBase <= step * kQB + 4u &&
                 rowBlk < __builtin_amdgcn_readfirstlane(sRowSync[0]) + kRowBufs) {
-                const uint32_t k = rowBlk * kCvtCols + ((uint32_t)lane >> 1);
-                const uint32_t off = (src_position(k, inc) + (kQLead - (kSrcWindow - 1))) & 3u;
+                const uint32_t k = kBase + rowBlk * kCvtCols + ((uint32_t)lane >> 1);
+                const uint32_t off = (src_position(k, inc) - nBase + (kQLead - (kSrcWindow - 1))) & 3u;
                 const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off + (lane & 1) * 16;
                 for (int q = 0; q < 4; q++) rq[q] = make_float4(pc[4 * q], pc[4 * q + 1], pc[4 * q + 2], pc[4 * q + 3]);
                 rowsInFlight = true;
@@ -245,6 +280,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     if (t == 3) thNext = q_take<1, kPart0>(thNext, ty);
                 }
                 thY = q_take<0, kPart0>(thY, thNext);
+                if (streaming && m + 1u == ntubeLane) st[2] = ty;
                 sX[(xbuf * kQB + part) * kXPitch + vq] = make_float4(E.gin, E.sig, ty, 0.0f);
             }
             STAMP_MID
@@ -261,6 +297,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // (area wave) frication band-pass memory as seen by this lane's slot, and what slots 0 / 1 start the
         // next block with
         float by1 = 0.0f, by2 = 0.0f, ny1 = 0.0f, ny2 = 0.0f, prevSig = 0.0f;
+        if (area && streaming && !sFirst) {
+            // st[4], st[5] = the band-pass outputs of positions -2, -1; st[6], st[7] = its inputs there
+            by1 = st[5];                                    // slot 0's y1
+            by2 = part == 0 ? st[4] : st[5];                // slot 0's y2, slot 1's y2
+            prevSig = part == 2 ? st[6] : st[7];            // slots 2, 3 of the "previous block"
+        }
         CoefTrack T;
         float prev[16], cur[16], nxt[16];
         uint32_t per = 0, j = (uint32_t)part;
@@ -330,6 +372,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 by2 = q_take<0, kPart0 | kPart1>(by2, ny2);
                 prevSig = sig;
                 xr[1] = f;
+                if (streaming) {
+                    const uint32_t n = (step - 2) * kQB + (uint32_t)part;
+                    if (n + 2u == ntubeLane) { st[4] = f; st[6] = sig; }
+                    if (n + 1u == ntubeLane) { st[5] = f; st[7] = sig; }
+                }
             }
             STAMP_MID
             step_barrier();
@@ -340,6 +387,21 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
         QuadState<float> S;
         quad_reset(S);
+        float *const stTube = streaming ? st + 104 + 20 * part : nullptr;
+        if (streaming && !sFirst) {
+            S.TA = v2f_t{stTube[0], stTube[1]}; S.TB = v2f_t{stTube[2], stTube[3]};
+            S.BA = v2f_t{stTube[4], stTube[5]}; S.BB = v2f_t{stTube[6], stTube[7]};
+            S.A0 = stTube[8]; S.jT = stTube[9]; S.jB = stTube[10]; S.jN = stTube[11];
+            S.eB = v2f_t{stTube[12], stTube[13]}; S.reflY = v2f_t{stTube[14], stTube[15]};
+            S.radX = v2f_t{stTube[16], stTube[17]}; S.radY = v2f_t{stTube[18], stTube[19]};
+        }
+        auto save_state = [&]() {
+            stTube[0] = S.TA.x; stTube[1] = S.TA.y; stTube[2] = S.TB.x; stTube[3] = S.TB.y;
+            stTube[4] = S.BA.x; stTube[5] = S.BA.y; stTube[6] = S.BB.x; stTube[7] = S.BB.y;
+            stTube[8] = S.A0; stTube[9] = S.jT; stTube[10] = S.jB; stTube[11] = S.jN;
+            stTube[12] = S.eB.x; stTube[13] = S.eB.y; stTube[14] = S.reflY.x; stTube[15] = S.reflY.y;
+            stTube[16] = S.radX.x; stTube[17] = S.radX.y; stTube[18] = S.radY.x; stTube[19] = S.radY.y;
+        };
         float4 *const ring = reinterpret_cast<float4 *>(&sY[vq * kYStride]);
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
         // one sample's inputs: {gin, band-pass output, throat output}, end coefficients, this part's record
@@ -373,11 +435,17 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const In i1 = load_in(blk, 1), i2 = load_in(blk, 2), i3 = load_in(blk, 3);
                 float y[kQB];
                 // (samples past nTotal in the last block step on stale inputs; their output is forced to 0)
+                // (streaming: the state after the chunk's last sample is what the next chunk starts from)
+                const bool saveHere = streaming && n0 < ntubeLane && n0 + kQB >= ntubeLane;      // uniform
                 y[0] = step_one(head);
+                if (saveHere && n0 + 1 == ntubeLane) save_state();
                 y[1] = step_one(i1);
+                if (saveHere && n0 + 2 == ntubeLane) save_state();
                 y[2] = step_one(i2);
+                if (saveHere && n0 + 3 == ntubeLane) save_state();
                 head = load_in(blk + 1, 0);
                 y[3] = step_one(i3);
+                if (saveHere && n0 + 4 == ntubeLane) save_state();
                 if (n0 + kQB > ntubeMin) {     // (uniform) zero flush / voices shorter than the group's longest
 #pragma unroll
                     for (int s = 0; s < kQB; s++) y[s] = n0 + s < ntubeLane ? y[s] : 0.0f;
@@ -389,7 +457,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     ring[slot4] = yy;
                     if (slot4 < (uint32_t)(kYMirror / 4)) ring[slot4 + kYRing / 4] = yy;
                     if (tubeOut && laneValid) {
-                        const uint32_t lim = ntubeLane + 2u * (uint32_t)C.padSize;
+                        const uint32_t lim = ntubeLane + (sLast ? 2u * (uint32_t)C.padSize : 0u);
                         for (int s = 0; s < kQB; s++)
                             if (n0 + s < lim) tubeOut[n0 + s] = y[s];
                     }
@@ -405,7 +473,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     } else {
         // ------------------------------------------------------------ convert (lane = output time), 16 voices
         uint32_t noutLane = 0;
-        if (nfr > 0) {
+        if (streaming) {
+            noutLane = A.stream_k_end - kBase;
+        } else if (nfr > 0) {
             uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
             noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
         }
@@ -427,10 +497,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         v2f cc[16];
         uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..3) of block `blk`: voices 4*pr .. 4*pr+3
         uint32_t winBase = 0, kLane = 0, needLast = 0;
+        // kLane = this lane's output within the launch; its global index is kBase + kLane, and ring positions are
+        // relative to the launch's first tube sample (nBase)
         auto begin_block = [&]() {
             kLane = blk * kCvtCols + col;
-            winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
-            needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
+            winBase = (src_position(kBase + kLane, inc) - nBase + kRingShift) & (kYRing - 1) & ~3u;
+            needLast = src_position(kBase + blk * kCvtCols + (kCvtCols - 1), inc) - nBase;
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
             const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk % kRowBufs) * (kCvtCols * kRowPitch) + col * kRowPitch]);
             for (int q = 0; q < 8; q++) {
@@ -441,10 +513,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         };
         auto begin_block_from_global = [&]() {
             kLane = blk * kCvtCols + col;
-            winBase = (src_position(kLane, inc) + kRingShift) & (kYRing - 1) & ~3u;
+            winBase = (src_position(kBase + kLane, inc) - nBase + kRingShift) & (kYRing - 1) & ~3u;
             needLast = nTotal - 1;
-            const uint32_t off = (src_position(kLane, inc) + kRingShift) & 3u;
-            const float *pc = A.src_rows + (size_t)src_phase(kLane, inc) * kSrcRowC - off;
+            const uint32_t off = (src_position(kBase + kLane, inc) - nBase + kRingShift) & 3u;
+            const float *pc = A.src_rows + (size_t)src_phase(kBase + kLane, inc) * kSrcRowC - off;
             for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
         };
         bool needBegin = nBlocks > 0;
@@ -538,6 +610,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 do_pair();
             }
         }
+        if (streaming && laneValid && part < 2) {
+            // the chunk's last 32 tube samples (positions N-32 .. N-1) for the next chunk's converter
+            for (int t = part; t < 32; t += 2)
+                st[72 + t] = sY[vq * kYStride + ((ntubeLane - 32u + (uint32_t)t + kQLead) & (kYRing - 1))];
+        }
         float myMax = 0.0f;     // collected by lanes 0..15: voice `lane` of the workgroup
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -551,7 +628,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         if (lane < kQV && ov < A.nvoices && C.upsample) {
             const uint32_t nf = A.nframes[ov];
             uint32_t nov = 0;
-            if (nf > 0) nov = (uint32_t)((((uint64_t)(nf - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);
+            if (streaming) nov = A.stream_k_end - kBase;
+            else if (nf > 0) nov = (uint32_t)((((uint64_t)(nf - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);
             A.number_samples[ov] = nov;
             A.max_sample[ov] = myMax;
         }
@@ -563,14 +641,17 @@ hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t strea
 {
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kQV - 1) / kQV;
-    hipLaunchKernelGGL(trm_tube_kernel_q, dim3(grid), dim3(kWave * kQRoles), 0, stream, c, a);
+    if (a.stream_state)
+        hipLaunchKernelGGL(trm_tube_kernel_q<true>, dim3(grid), dim3(kWave * kQRoles), 0, stream, c, a);
+    else
+        hipLaunchKernelGGL(trm_tube_kernel_q<false>, dim3(grid), dim3(kWave * kQRoles), 0, stream, c, a);
     return hipGetLastError();
 }
 
 int tube_quad_kernel_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel_q, kWave * kQRoles, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel_q<false>, kWave * kQRoles, 0) != hipSuccess) return -1;
     return n;
 }
 

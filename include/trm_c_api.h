@@ -243,6 +243,36 @@ int  trm_batch_generate_frames_host(trm_batch *batch, const uint32_t *event_time
                                     size_t nevents, const trm_intonation *settings,
                                     float *frames_out, size_t frames_cap, size_t *nframes);
 
+/* ---------------------------------------------------------------------------------------------
+ * Streaming synthesis: an utterance delivered in chunks of control frames, PCM returned
+ * per chunk, with the tube, oscillator, filter and converter state carried on the device from one chunk to
+ * the next.  How the utterance is cut into chunks does not matter, bit for bit, and the streamed utterance
+ * equals what trm_batch_synthesize_* returns for it at once to rounding (same sample count; both tested), so a
+ * server can start playing after the first chunk.
+ *
+ * This is also what TRAcT's real-time loop needs (Applications/TRAcT/tube.c:1096-1190: a thread that keeps
+ * synthesizing from the `current` parameter set into a circular buffer the CoreAudio callback drains,
+ * tube.c:2348-2420, Controller.m:73-100): shim/tract_tube.c implements tube.h's setters/getters over a
+ * one-voice stream and pushes the current parameters every control period.
+ *
+ * All voices of a stream advance together (same number of frames per push).  Up-sampling voices only
+ * (tube rate below the output rate: every shipped voice); the four-lane kernel form carries it. */
+typedef struct trm_stream trm_stream;
+int  trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out);
+void trm_stream_destroy(trm_stream *stream);
+/* Exact number of samples per voice the next push of `nframes` frames (resp. the finish call) returns. */
+size_t trm_stream_samples_for_push(const trm_stream *stream, size_t nframes);
+size_t trm_stream_samples_for_finish(const trm_stream *stream);
+/* frames: fp32 [nvoices][nframes][16], host.  The first frame ever pushed is the utterance's starting point;
+ * every later frame adds one control period (interpolated from the frame before it, TRMTubeModel.m:611-688).
+ * out: fp32 [nvoices][out_pitch] host, out_pitch >= trm_stream_samples_for_push; *nout = samples per voice;
+ * max_out[v] (optional) = max |sample| of voice v in this chunk. */
+int  trm_stream_push(trm_stream *stream, const float *frames, size_t nframes, float *out, size_t out_pitch,
+                     uint32_t *nout, float *max_out);
+/* The converter's flush (TRMSampleRateConverter.m:155-168): the last samples of the utterance.  The stream
+ * can then start a new utterance with its next push. */
+int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_t *nout, float *max_out);
+
 /* Kernel form of the synthesis launch.  Both forms compute the same samples (same arithmetic per value);
  * they differ in how a voice is laid out on the machine:
  *   TRM_KERNEL_WIDE  one voice per lane, 64 voices per workgroup: highest throughput once the batch fills

@@ -1,0 +1,95 @@
+"""Streaming synthesis (include/trm_c_api.h trm_stream_*): HOW an utterance is cut into chunks does
+not matter, BIT FOR BIT (tube, oscillator, FIR, band-pass, throat and converter state are carried on the device;
+chunk boundaries fall anywhere relative to the kernel's 4-sample steps and to the converter's 32-output blocks), and
+the streamed utterance equals the one-shot batch path to rounding (the streaming kernel is a separate compile-time
+instance of the same source: the compiler fuses multiply-adds differently in the two, so the last bits differ)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gnuspeech_amd
+    assert gnuspeech_amd.lib().trm_device_count() >= 1
+    return gnuspeech_amd
+
+
+def nrms(x, ref, mx):
+    if mx == 0.0:                                   # a silent voice: both must be silent
+        return 0.0 if not np.any(x) and not np.any(ref) else np.inf
+    e = (np.asarray(x, dtype=np.float64) - np.asarray(ref, dtype=np.float64)) / mx
+    return float(np.sqrt(np.mean(e * e)))
+
+
+def stream_all(g, pd, fr, chunks):
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=fr.shape[0])
+    parts, maxes, pos = [], [], 0
+    for c in chunks:
+        out, m = s.push(fr[:, pos:pos + c])
+        parts.append(out)
+        maxes.append(m)
+        pos += c
+    out, m = s.finish()
+    parts.append(out)
+    maxes.append(m)
+    return np.concatenate(parts, axis=1), np.max(np.stack(maxes), axis=0), s
+
+
+def one_shot(g, pd, frames):
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    b.set_kernel("quad")
+    pcm, ns, mx = b.synthesize(list(frames))
+    return pcm, ns, mx
+
+
+@pytest.mark.parametrize("rate,chunks", [(44100.0, [5, 1, 1, 17, 2, 30, 4]), (22050.0, [60]), (44100.0, [1] * 12 + [48]),
+                                          (22050.0, [2, 58])])
+def test_chunked_equals_one_shot(g, rate, chunks):
+    pd = cases.monet_default_params(rate)
+    V, n = 21, sum(chunks)
+    fr = cases.config3_frames(V, nframes=n).astype(np.float32)
+    whole, whole_max, _ = stream_all(g, pd, fr, [n])                 # the utterance in one push
+    got, got_max, _ = stream_all(g, pd, fr, chunks)
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+    assert np.array_equal(got_max, whole_max)
+    pcm, ns, mx = one_shot(g, pd, fr)                                 # the batch path
+    assert got.shape[1] == int(ns[0])
+    for v in range(V):
+        assert nrms(got[v], pcm[v], mx[v]) <= 2e-6, "voice %d" % v
+    assert np.allclose(got_max, mx, rtol=1e-4)
+
+
+def test_second_utterance_starts_from_rest(g):
+    pd = cases.monet_default_params(44100.0)
+    fr = cases.config3_frames(3, nframes=20).astype(np.float32)
+    pcm, ns, mx = one_shot(g, pd, fr)
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=3)
+    first = None
+    for _ in range(2):
+        a, _m = s.push(fr[:, :9])
+        b, _m = s.push(fr[:, 9:])
+        c, _m = s.finish()
+        got = np.concatenate([a, b, c], axis=1)
+        if first is None:
+            first = got
+        assert np.array_equal(got, first)                 # the second utterance starts from rest like the first
+        for v in range(3):
+            assert nrms(got[v], pcm[v], mx[v]) <= 2e-6
+
+
+def test_held_parameters_like_tract(g):
+    """TRAcT's real-time loop keeps synthesizing from the current parameter set: pushing the same frame every control
+    period gives the steady vowel the one-shot path gives for static frames."""
+    pd = cases.tract_default_params()
+    fr = cases.static_frames(cases.TRACT_VOWEL_FRAME, 40).astype(np.float32)
+    pcm, ns, mx = one_shot(g, pd, [fr])
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=1)
+    parts = [s.push(fr[i:i + 1])[0] for i in range(40)]
+    parts.append(s.finish()[0])
+    got = np.concatenate(parts, axis=1)[0]
+    assert got.size == int(ns[0]) and nrms(got, pcm[0], mx[0]) <= 2e-6
+    assert np.all(np.isfinite(got)) and np.abs(got).max() > 0

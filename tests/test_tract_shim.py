@@ -1,0 +1,53 @@
+"""shim/tract_tube.c: TRAcT's tube.h interface over a one-voice stream.  The C shim is compiled with
+gcc, driven like Controller.m drives tube.c (initializeSynthesizer, getCircBuff2, parameter writes through the getter
+pointers), and what comes out of its circular buffer is compared with the same held parameters pushed through the
+Python TRMStream mirror (bit for bit, x100 as tube.c:1180 scales)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tract_shim_plays_held_parameters(tmp_path):
+    import gnuspeech_amd as g
+    exe = str(tmp_path / "tract_shim_driver")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tests", "tract_shim_driver.c"),
+                           os.path.join(ROOT, "shim", "tract_tube.c"), "-L" + os.path.join(ROOT, "gnuspeech_amd"),
+                           "-l:libtrm_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "gnuspeech_amd"), "-lpthread", "-lm"])
+    out = str(tmp_path / "heard.f32")
+    n1, n2 = 30000, 30000
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, out, str(n1), str(n2)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    heard = np.fromfile(out, dtype=np.float32)
+    assert heard.size == n1 + n2 and np.all(np.isfinite(heard))
+    # the same held "ee" posture through the Python mirror of the stream API
+    # the shim's utterance-rate globals (shim/tract_tube.c, from Applications/TRAcT/tube.c:326-352)
+    pd = dict(outputFileFormat=1, outputRate=44100.0, controlRate=100.0, volume=60.0, channels=2, balance=0.0, waveform=0,
+              tp=35.0, tnMin=16.0, tnMax=40.0, breathiness=2.5, length=17.0, temperature=32.0, lossFactor=0.8, apScale=2.5,
+              mouthCoef=4000.0, noseCoef=4000.0, noseRadius=[1.35, 1.35, 1.7, 1.7, 1.3, 0.9], throatCutoff=1500.0,
+              throatVol=6.0, usesModulation=1, mixOffset=48.0)
+    frame = np.array([-0.0, 60, 0, 0, 8, 5000, 250, 0.8, 1.67, 1.905, 1.985, 0.81, 0.495, 0.73, 1.485, 0], dtype=np.float32)
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=1)
+    parts, total = [], 0
+    while total < n1:
+        o, _ = s.push(frame[None, None, :])
+        parts.append(o[0])
+        total += o.shape[1]
+    want = np.concatenate(parts)[:n1] * np.float32(100.0)
+    assert "controlPeriod %d" % s_derived_cp(g, pd) in r.stdout
+    assert np.array_equal(heard[:n1], want)
+    # after the parameter change the voice is still sounding, at another pitch: the spectrum moved
+    a, b = heard[n1 - 16384:n1], heard[-16384:]
+    assert np.abs(b).max() > 0.01 * np.abs(a).max()
+    fa, fb = np.abs(np.fft.rfft(a * np.hanning(a.size))), np.abs(np.fft.rfft(b * np.hanning(b.size)))
+    assert abs(int(np.argmax(fa[5:2000])) - int(np.argmax(fb[5:2000]))) > 3
+
+
+def s_derived_cp(g, pd):
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    return b.derived["controlPeriod"]
