@@ -183,10 +183,10 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipMalloc((void **)&b->dConst, sizeof(trm::Const)));
     B_TRY(hipMemcpy(b->dConst, &b->c, sizeof(trm::Const), hipMemcpyHostToDevice));
     // 4 zero floats in front of row 0: the convert stage fetches rows shifted by up to 3 floats
-    // [64 floats of write-only sink for masked converter lanes][4 zeros in front of row 0][rows]
-    B_TRY(hipMalloc((void **)&b->dRowsAlloc, (rows.size() + 68) * sizeof(float)));
-    B_TRY(hipMemset(b->dRowsAlloc, 0, 68 * sizeof(float)));
-    b->dRows = b->dRowsAlloc + 68;
+    // [4 zeros in front of row 0: the shifted fetch of a row reads up to 3 floats before it][rows]
+    B_TRY(hipMalloc((void **)&b->dRowsAlloc, (rows.size() + 4) * sizeof(float)));
+    B_TRY(hipMemset(b->dRowsAlloc, 0, 4 * sizeof(float)));
+    b->dRows = b->dRowsAlloc + 4;
     B_TRY(hipMemcpy(b->dRows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dSine, sine.size() * sizeof(float)));
     B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -299,7 +299,6 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     a.sine = b->dSine;
     a.nvoices = (uint32_t)nvoices;
     a.stamps = nullptr;
-    a.sink = b->dRowsAlloc;
     a.stream_state = nullptr;
     a.stream_flags = a.stream_n_base = a.stream_k_base = a.stream_k_end = 0;
     a.tube_out = nullptr;
@@ -489,8 +488,7 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         a.tube_offset = nullptr;
         a.nvoices = (uint32_t)V;
         a.stamps = nullptr;
-        a.sink = b->dRowsAlloc;
-        a.stream_state = s->dState.p;
+            a.stream_state = s->dState.p;
         a.stream_flags = (s->first ? 1u : 0u) | (flush ? 2u : 0u);
         a.stream_n_base = (uint32_t)s->nBase;
         a.stream_k_base = (uint32_t)s->kBase;

@@ -33,7 +33,6 @@ struct TubeArgs {
     const uint64_t *tube_offset;
     uint32_t nvoices;
     unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product
-    float *sink;                  // (unused)
     // Streaming (trm_tube_kernel_q only): a chunk of a longer utterance.  Null for one-shot synthesis.
     //   stream_state   kStreamFloats floats per voice, carried from one chunk to the next
     //   stream_flags   bit 0: first chunk (state ignored: the tube starts at rest, the converter with its 25 zeros

@@ -137,9 +137,6 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             if (step * kQB < nTotal) {
-#ifdef TRM_ABL_NOSETUP
-                if (j >= CP) j -= CP;
-#endif
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
                     j -= CP;
                     per++;
@@ -317,9 +314,6 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             STAMP_BEGIN
             if (step >= 1 && (step - 1) * kQB < nTotal) {
                 const int buf = (step - 1) % kQBufs;
-#ifdef TRM_ABL_NOSETUP
-                if (j >= CP) j -= CP;
-#endif
                 if (j >= CP) {
                     j -= CP;
                     per++;
