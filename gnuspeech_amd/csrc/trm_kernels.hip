@@ -2,11 +2,13 @@
 //
 //   trm_noise_kernel      the voice-independent noise sequence (TRMUtility.m:71-85 + TRMFilters.m:81-86),
 //                         fp64 serial recurrence, one lane, run once per batch object and cached
-//   trm_tube_kernel       -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361): one tube per lane, 64 voices
-//                         per workgroup, 4 waves per workgroup running the sample loop as a pipeline
-//                         (excite | coef | tube | convert) with hand-offs through LDS; state in VGPRs;
-//                         wave-uniform control in SGPRs; converter coefficients + noise prefetched into
-//                         LDS rings by LDS-DMA one half ahead; output staged through LDS, written as rows
+//   trm_tube_kernel       -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361), one tube per lane: 64 voices
+//                         per workgroup, 7 waves per workgroup running the sample loop as a pipeline
+//                         (osc | mix | coef x2 | tube | convert x2) with hand-offs through LDS; state in
+//                         VGPRs; wave-uniform control in SGPRs; noise prefetched into an LDS ring by LDS-DMA;
+//                         PCM written as rows straight from registers.  The form for batches that fill the
+//                         chip; smaller ones run trm_quad.hip's four-lanes-per-voice form.
+//   trm_downsample_kernel the converter's down-sampling branch (TRMSampleRateConverter.m:234-297)
 //   trm_int16_kernel      output normalisation (TRMTubeModel.m:370-389, 420-484)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,10 +48,10 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
     state[1] = x1;
 }
 
-// One workgroup = 64 voices x 6 waves.
-//   excite, coef x2, tube: lane = voice.  At step i the excite wave and the two coef waves (one per
-//     sample parity; the coefficient stage is stateless in time) produce block i (kTB tube samples)
-//     into LDS, the tube wave consumes block i-1 and appends its tube-rate samples to a per-voice ring
+// One workgroup = 64 voices x 7 waves.
+//   osc, mix, coef x2, tube: lane = voice.  At step i the osc wave produces block i (kTB tube samples), the
+//     mix wave and the two coef waves (one per sample parity; the coefficient stage is stateless in time)
+//     block i-1, the tube wave consumes block i-2 and appends its tube-rate samples to a per-voice ring
 //     in LDS.  Hand-off buffers are double-buffered; one barrier per step.
 //   convert x2: lane = OUTPUT TIME.  The converter is a feed-forward FIR, so it runs transposed: a
 //     wave-row is 32 consecutive output samples of two voices (lanes 0-31 / 32-63).  All 64 voices

@@ -66,3 +66,37 @@ def test_product_fails_loudly_without_gpu():
     with pytest.raises(g.TrmError) as ei:
         g.TRMTubeModel.initWithInputData(dl)
     assert ei.value.code == 6                                      # TRM_ENODEVICE
+
+
+def test_sound_file_writer_against_oracle_scaling(tmp_path):
+    """trm_write_sound_file (-saveOutputToFile:error:, TRMTubeModel.m:365-490) is host-side container code: AU / AIFF /
+    WAVE headers and the int16 payload must be what the oracle's restatement of the scaling produces (mono and stereo)."""
+    import ctypes as C
+    import gnuspeech_amd as g
+    import oracle_lib as O
+    L = g.lib()
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(1000) * 0.01).astype(np.float32)
+    mx = float(np.abs(x).max())
+    for channels, balance in ((1, 0.0), (2, -0.25)):
+        for fmt, (magic, hdr, dt) in {0: (b".snd", 24, ">i2"), 1: (b"FORM", 54, ">i2"), 2: (b"RIFF", 44, "<i2")}.items():
+            pd = dict(cases.monet_default_params(22050.0), outputFileFormat=fmt, channels=channels, balance=balance, volume=57.0)
+            ip = g.TRMInputParameters.from_dict(pd)
+            path = str(tmp_path / ("x%d_%d" % (channels, fmt)))
+            assert L.trm_write_sound_file(C.byref(ip.c), x.ctypes.data, x.size, mx, path.encode()) == 0
+            raw = open(path, "rb").read()
+            assert raw[:4] == magic and len(raw) == hdr + 2 * channels * x.size
+            body = np.frombuffer(raw[hdr:], dtype=dt).astype(np.int32)
+            ref = O.scale_int16(O.InputParams.from_dict(pd), x.astype(np.float64), mx).astype(np.int32)
+            diff = ((body - ref + 32768) % 65536) - 32768          # the file path's x2 stereo gain wraps like the reference's cast
+            assert np.max(np.abs(diff)) == 0
+
+
+def test_event_frame_count_needs_no_gpu():
+    import ctypes as C
+    import gnuspeech_amd as g
+    s = g._capi.TrmIntonation()
+    times = np.array([0, 40, 100], dtype=np.uint32)
+    n = C.c_size_t()
+    assert g.lib().trm_events_count_frames(times.ctypes.data, 3, C.byref(s), C.byref(n)) == 0
+    assert n.value == 25                                           # t = 0, 4, ..., 96
