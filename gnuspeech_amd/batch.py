@@ -77,18 +77,22 @@ class TRMBatch:
             foff[1:V] = np.cumsum(nfr[:-1])
         lut = {int(n): self.samples_for_frames(int(n)) for n in np.unique(nfr)}
         nout_v = np.array([lut[int(n)] for n in nfr], dtype=np.int64)
+        # every voice's PCM starts on a 128-byte boundary: the converter stores rows of 32 samples, and a row
+        # that straddles two cache lines costs two partial writes instead of one full line
+        pitch_v = (nout_v + 31) // 32 * 32
         ooff = np.zeros(max(1, V), dtype=np.int64)
         if V > 1:
-            ooff[1:V] = np.cumsum(nout_v[:-1])
+            ooff[1:V] = np.cumsum(pitch_v[:-1])
         dev = torch.device(device)
         return {
             "V": V, "max_nframes": int(nfr.max()) if V else 0, "total_out": int(nout_v.sum()),
+            "out_alloc": int(pitch_v.sum()),
             "nout": nout_v, "out_offset_host": ooff, "nframes_host": nfr,
             "frames": torch.from_numpy(flat if flat.size else np.zeros((1, 16), np.float32)).to(dev),
             "frame_offset": torch.from_numpy(foff).to(dev),
             "nframes": torch.from_numpy(nfr.astype(np.int32) if V else np.zeros(1, np.int32)).to(dev),
             "out_offset": torch.from_numpy(ooff).to(dev),
-            "out": torch.zeros(max(1, int(nout_v.sum())), dtype=torch.float32, device=dev),
+            "out": torch.zeros(max(1, int(pitch_v.sum())), dtype=torch.float32, device=dev),
             "number_samples": torch.zeros(max(1, V), dtype=torch.int32, device=dev),
             "max_sample": torch.zeros(max(1, V), dtype=torch.float32, device=dev),
         }
@@ -145,7 +149,7 @@ class TRMBatch:
         import torch
         s = stream if stream is not None else torch.cuda.current_stream()
         ch = 2 if self.inputParameters.channels == 2 else 1
-        pcm16 = torch.zeros(max(1, st["total_out"] * ch), dtype=torch.int16, device=st["out"].device)
+        pcm16 = torch.zeros(max(1, st["out_alloc"] * ch), dtype=torch.int16, device=st["out"].device)
         check(lib().trm_batch_scale_to_int16_device(
             self._h, st["V"], st["out"].data_ptr(), st["out_offset"].data_ptr(), st["number_samples"].data_ptr(),
             st["max_sample"].data_ptr(), pcm16.data_ptr(), int(for_wav_data), C.c_void_p(s.cuda_stream)))

@@ -20,6 +20,10 @@
 #include "trm_lane.h"
 #include "trm_quad.h"
 
+#ifndef TRM_ABL_CVT
+#define TRM_ABL_CVT 0
+#endif
+
 namespace trm {
 
 constexpr int kQV = 16;              // voices per workgroup
@@ -535,7 +539,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             v2f a0, a1, b0, b1;
             {
                 float4 q[8];
+#if TRM_ABL_CVT == 2      /* (timing experiments: 2 = one ring read per row instead of eight) */
+                q[0] = wa[0];
+                for (int i = 1; i < 8; i++) q[i] = make_float4(q[0].y, q[0].z, q[0].w, q[0].x + (float)i);
+#else
                 for (int i = 0; i < 8; i++) q[i] = wa[i];
+#endif
                 a0 = v2f{q[0].x, q[0].y} * cc[0];
                 a1 = v2f{q[0].z, q[0].w} * cc[1];
                 for (int i = 1; i < 8; i++) {
@@ -545,7 +554,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             }
             {
                 float4 q[8];
+#if TRM_ABL_CVT == 2
+                q[0] = wb[0];
+                for (int i = 1; i < 8; i++) q[i] = make_float4(q[0].y, q[0].z, q[0].w, q[0].x + (float)i);
+#else
                 for (int i = 0; i < 8; i++) q[i] = wb[i];
+#endif
                 b0 = v2f{q[0].x, q[0].y} * cc[0];
                 b1 = v2f{q[0].z, q[0].w} * cc[1];
                 for (int i = 1; i < 8; i++) {
@@ -557,8 +571,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             b0 += b1;
             const float ya = a0.x + a0.y, yb = b0.x + b0.y;
             const bool okA = kLane < ia.x, okB = kLane < ib.x;
+#if TRM_ABL_CVT != 1      /* (timing experiments: 1 = no PCM stores) */
             if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ia.z << 32) | ia.y)[kLane] = ya;
             if (okB) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ib.z << 32) | ib.y)[kLane] = yb;
+#endif
             __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMx[(2 * pr) * kWave + lane], okA ? fabsf(ya) : 0.0f, 0, 0, false);
             __builtin_amdgcn_ds_fmaxf((LdsFloatPtr)&sMx[(2 * pr + 1) * kWave + lane], okB ? fabsf(yb) : 0.0f, 0, 0, false);
             if (++pr == 4) {

@@ -218,5 +218,5 @@ def test_gpu_ragged_batch_events_to_pcm(g):
     b.synthesize_device(st2)
     torch.cuda.synchronize()
     assert np.array_equal(st["number_samples"].cpu().numpy(), st2["number_samples"].cpu().numpy())
-    assert np.all(np.isfinite(pcm_a[:st["total_out"]]))
-    assert np.array_equal(pcm_a[:st["total_out"]], st2["out"].cpu().numpy()[:st2["total_out"]])
+    assert st["out_alloc"] == st2["out_alloc"] and np.all(np.isfinite(pcm_a[:st["out_alloc"]]))
+    assert np.array_equal(pcm_a[:st["out_alloc"]], st2["out"].cpu().numpy()[:st2["out_alloc"]])

@@ -293,7 +293,7 @@ def test_full_size_properties(g, form):
     torch.cuda.synchronize()
     ns = st["number_samples"].cpu().numpy()
     assert np.all(ns == 44159)
-    out = st["out"].cpu().numpy().reshape(4096, 44159)
+    out = st["out"].cpu().numpy().reshape(4096, st["out_alloc"] // 4096)[:, :44159]      # rows start on 128-byte boundaries
     assert np.all(np.isfinite(out))
     assert np.array_equal(out[0], out[4095]) and np.array_equal(out[0], out[2049])
     mx = st["max_sample"].cpu().numpy()
