@@ -529,6 +529,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         const uint32_t creditCap = (capPairs > 2u ? capPairs : 2u) << 16;   // two pairs per step at speech rates (earn ~ 1.1)
         uint32_t credit = 0;
         auto do_pair = [&]() {
+#if TRM_ABL_CVT == 3      /* (timing experiments: 3 = the converter's control flow only) */
+            if (++pr == 4) { pr = 0; blk++; needBegin = blk < nBlocks; }
+            return;
+#endif
             const int la = 4 * (int)pr, lb = la + 2;
             const int ha = upper ? 1 : 0;
             const float4 *wa = reinterpret_cast<const float4 *>(&sY[(la + ha) * kYStride + winBase]);
