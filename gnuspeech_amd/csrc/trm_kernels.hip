@@ -318,6 +318,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         uint32_t winBase = 0;           // this lane's aligned window start inside a voice's ring (floats)
         uint32_t kLane = 0;             // this lane's output index
         uint32_t needLast = 0;          // last tube sample the current block reads (uniform)
+        uint32_t needNext = 0;          // ... and the one after it: complete already = this wave is a block behind
         auto begin_block = [&]() {
             kLane = blk * kCvtCols + col;
             winBase = src_position(kLane, inc) & (kYRing - 1) & ~3u;
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             // the longest voice's end are masked, so the last block only waits for the final sample
             needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
+            needNext = src_position((blk + 1) * kCvtCols + (kCvtCols - 1), inc);     // (past the end: never "behind")
             fetch_row(blk);
         };
         if (nBlocks > 0) begin_block();
@@ -386,8 +388,11 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             const uint32_t ready = step >= 2 ? (step - 2) * kTB : 0;
             credit += earn;
             if (credit > creditCap) credit = creditCap;     // a ready block is spread over the next steps, not done in a burst
-            while (credit >= (1u << 16) && blk < nBlocks && needLast < ready) {
-                credit -= 1u << 16;
+            // Metered by the credit (smooth: at most creditCap pairs in a step) -- but a wave that is a whole block
+            // behind production works through its backlog regardless: the credit alone loses what it earns while it
+            // waits for a block to complete, and at some rate ratios that slowly let the ring lap the converter.
+            while (blk < nBlocks && needLast < ready && (credit >= (1u << 16) || needNext < ready)) {
+                credit = credit >= (1u << 16) ? credit - (1u << 16) : credit;
                 do_pair();
             }
             STAMP_MID

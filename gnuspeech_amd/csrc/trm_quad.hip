@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // counter also counts its PCM stores); a block begins by copying this lane's row into registers.
         v2f cc[16];
         uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..3) of block `blk`: voices 4*pr .. 4*pr+3
-        uint32_t winBase = 0, kLane = 0, needLast = 0;
+        uint32_t winBase = 0, kLane = 0, needLast = 0, needNext = 0;
         // kLane = this lane's output within the launch; its global index is kBase + kLane, and ring positions are
         // relative to the launch's first tube sample (nBase)
         auto begin_block = [&]() {
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             winBase = (src_position(kBase + kLane, inc) - nBase + kRingShift) & (kYRing - 1) & ~3u;
             needLast = src_position(kBase + blk * kCvtCols + (kCvtCols - 1), inc) - nBase;
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
+            needNext = src_position(kBase + (blk + 1) * kCvtCols + (kCvtCols - 1), inc) - nBase;   // (past the end: never "behind")
             const float4 *row = reinterpret_cast<const float4 *>(&sRows[(blk % kRowBufs) * (kCvtCols * kRowPitch) + col * kRowPitch]);
             for (int q = 0; q < 8; q++) {
                 const float4 x = row[q];
@@ -603,8 +604,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 }
             };
             if (needBegin) try_begin();
-            while (credit >= (1u << 16) && blk < nBlocks && !needBegin && needLast < ready) {
-                credit -= 1u << 16;
+            // Metered by the credit (smooth: at most creditCap pairs in a step) -- but a wave that is a whole block
+            // behind production works through its backlog regardless: the credit alone loses what it earns while it
+            // waits for a block to complete, and at some rate ratios that slowly let the ring lap the converter.
+            while (blk < nBlocks && !needBegin && needLast < ready && (credit >= (1u << 16) || needNext < ready)) {
+                credit = credit >= (1u << 16) ? credit - (1u << 16) : credit;
                 do_pair();
                 if (needBegin) try_begin();
             }

@@ -149,6 +149,33 @@ def test_short_control_periods(g, form):
         _batch_vs_oracle(g, pd, voices)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_voices_and_tracks(g, form, seed):
+    """Random utterance-rate parameters inside the ranges the reference's editors allow (Monet's synthesis-parameter
+    panel / TRAcT's sliders) with random time-varying tracks: tube lengths from child to giant (both converter
+    branches), either waveform, modulation on and off, any control rate from 100 to 1000 Hz."""
+    rng = np.random.default_rng(1000 + seed)
+    pd = cases.monet_default_params(float(rng.choice([22050.0, 44100.0])))
+    pd.update(controlRate=float(rng.choice([100.0, 250.0, 500.0, 1000.0])), waveform=int(rng.integers(0, 2)),
+              tp=float(rng.uniform(20, 45)), tnMin=float(rng.uniform(8, 20)), breathiness=float(rng.uniform(0, 10)),
+              length=float(rng.uniform(11.0, 24.0)), temperature=float(rng.uniform(25, 40)), lossFactor=float(rng.uniform(0.1, 3.0)),
+              apScale=float(rng.uniform(1.5, 5.0)), mouthCoef=float(rng.uniform(2000, 6000)), noseCoef=float(rng.uniform(2000, 6000)),
+              noseRadius=[0.0] + [float(x) for x in rng.uniform(0.5, 2.5, 5)], throatCutoff=float(rng.uniform(500, 3000)),
+              throatVol=float(rng.uniform(0, 24)), usesModulation=int(rng.integers(0, 2)), mixOffset=float(rng.uniform(30, 60)))
+    pd["tnMax"] = pd["tnMin"] + float(rng.uniform(5, 20))
+    voices = []
+    for _ in range(5):
+        n = int(rng.integers(2, 60))
+        knots = max(2, n // 8)
+        t = np.linspace(0, knots - 1, n)
+        def track(lo, hi):
+            return np.interp(t, np.arange(knots), rng.uniform(lo, hi, knots))
+        fr = np.stack([track(-10, 6), track(0, 60), track(0, 20), track(0, 40), track(0, 7), track(500, 5000), track(200, 2500)]
+                      + [track(0.05, 2.5) for _ in range(8)] + [track(0.0, 1.2)], axis=1)
+        voices.append(fr)
+    _batch_vs_oracle(g, pd, voices, tol=2e-5)
+
+
 def test_tract_defaults_and_sine(g, form):
     rows = cases.load_gnuspeech_rows()
     _batch_vs_oracle(g, cases.tract_default_params(), [cases.static_frames(cases.TRACT_VOWEL_FRAME, 21)])
