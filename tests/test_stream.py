@@ -93,3 +93,25 @@ def test_held_parameters_like_tract(g):
     got = np.concatenate(parts, axis=1)[0]
     assert got.size == int(ns[0]) and nrms(got, pcm[0], mx[0]) <= 2e-6
     assert np.all(np.isfinite(got)) and np.abs(got).max() > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_parameters_and_chunkings(g, seed):
+    """Random voices (tube lengths, rates, control rates, waveforms) cut at random places: the cut never shows."""
+    rng = np.random.default_rng(700 + seed)
+    pd = cases.monet_default_params(float(rng.choice([22050.0, 44100.0])))
+    pd.update(controlRate=float(rng.choice([100.0, 250.0, 1000.0])), waveform=int(rng.integers(0, 2)),
+              length=float(rng.uniform(16.5, 28.0)), lossFactor=float(rng.uniform(0.1, 3.0)), usesModulation=int(rng.integers(0, 2)),
+              breathiness=float(rng.uniform(0, 10)), tp=float(rng.uniform(20, 45)))
+    V, n = int(rng.integers(1, 40)), int(rng.integers(8, 90))
+    fr = cases.config3_frames(V, nframes=n).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(1, n), size=min(n - 1, int(rng.integers(1, 9))), replace=False))
+    chunks = list(np.diff(np.concatenate([[0], cuts, [n]])))
+    whole, whole_max, _ = stream_all(g, pd, fr, [n])
+    got, got_max, _ = stream_all(g, pd, fr, chunks)
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), chunks
+    assert np.array_equal(got_max, whole_max)
+    pcm, ns, mx = one_shot(g, pd, fr)
+    assert got.shape[1] == int(ns[0])
+    for v in range(V):
+        assert nrms(got[v], pcm[v], mx[v]) <= 4e-6, "voice %d" % v

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Wider sweep of the randomized parity test (tests/test_gpu_parity.py::test_random_voices_and_tracks): more seeds,
+longer and more voices.  Prints every (seed, form, voice) above tolerance.   usage: fuzz_parity.py first last [maxframes]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import cases, oracle_lib as O
+import gnuspeech_amd as g
+first, last = int(sys.argv[1]), int(sys.argv[2])
+maxframes = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+bad = 0
+for seed in range(first, last):
+    rng = np.random.default_rng(5000 + seed)
+    pd = cases.monet_default_params(float(rng.choice([22050.0, 44100.0])))
+    pd.update(controlRate=float(rng.choice([100.0, 250.0, 500.0, 1000.0])), waveform=int(rng.integers(0, 2)),
+              tp=float(rng.uniform(20, 45)), tnMin=float(rng.uniform(8, 20)), breathiness=float(rng.uniform(0, 10)),
+              length=float(rng.uniform(10.0, 30.0)), temperature=float(rng.uniform(25, 40)), lossFactor=float(rng.uniform(0.1, 3.0)),
+              apScale=float(rng.uniform(1.5, 5.0)), mouthCoef=float(rng.uniform(2000, 6000)), noseCoef=float(rng.uniform(2000, 6000)),
+              noseRadius=[0.0] + [float(x) for x in rng.uniform(0.5, 2.5, 5)], throatCutoff=float(rng.uniform(500, 3000)),
+              throatVol=float(rng.uniform(0, 24)), usesModulation=int(rng.integers(0, 2)), mixOffset=float(rng.uniform(30, 60)))
+    pd["tnMax"] = pd["tnMin"] + float(rng.uniform(5, 20))
+    voices = []
+    for _ in range(int(rng.integers(1, 24))):
+        n = int(rng.integers(0, maxframes)); knots = max(2, n // 8); t = np.linspace(0, knots - 1, max(n, 1))
+        def track(lo, hi): return np.interp(t, np.arange(knots), rng.uniform(lo, hi, knots))
+        fr = np.stack([track(-10, 6), track(0, 60), track(0, 20), track(0, 40), track(0, 7), track(500, 5000), track(200, 2500)] + [track(0.05, 2.5) for _ in range(8)] + [track(0.0, 1.2)], axis=1)
+        voices.append(fr[:n])
+    op = O.InputParams.from_dict(pd)
+    ref = [O.synthesize(op, np.asarray(v, np.float32).astype(np.float64)) for v in voices]
+    for form in ("wide", "quad"):
+        try:
+            b = g.TRMBatch(g.TRMInputParameters.from_dict(pd)); b.set_kernel(form)
+            pcm, ns, mx = b.synthesize(voices)
+        except Exception as e:
+            print("seed %d %s: %s" % (seed, form, e)); bad += 1; continue
+        for v, o in enumerate(ref):
+            if int(ns[v]) != o["numberSamples"]:
+                print("seed %d %s voice %d: count %d vs %d" % (seed, form, v, ns[v], o["numberSamples"])); bad += 1; continue
+            if o["numberSamples"] == 0 or o["maximumSampleValue"] == 0: continue
+            e = (pcm[v].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
+            r = float(np.sqrt(np.mean(e * e)))
+            if not r <= 2e-5:
+                print("seed %d %s voice %d (%d frames, length %.1f, rate %.0f/%.0f): rms %.3e" % (seed, form, v, len(voices[v]), pd["length"], pd["outputRate"], pd["controlRate"], r)); bad += 1
+print("done: seeds %d..%d, %d findings" % (first, last, bad))
