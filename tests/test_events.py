@@ -181,6 +181,30 @@ def test_gpu_frames_equal_oracle_all_switches(g):
 
 
 @pytest.mark.gpu
+def test_gpu_frames_equal_oracle_irregular_event_times(g):
+    """Event times that are not multiples of the 4 ms frame interval, several events inside one interval (the
+    generator advances one event per frame, so it runs late and the unsigned `time - currentTime` of
+    EventList.m:1040-1041 wraps), and time ranges that cut the utterance."""
+    import cases
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params()))
+    rng = np.random.default_rng(41)
+    for trial in range(12):
+        n = int(rng.integers(2, 30))
+        times = np.concatenate([[0], np.cumsum(rng.integers(0, 11, size=n - 1))]).astype(np.uint32)     # incl. equal times
+        _, vals = random_events(rng, n, smooth=bool(trial & 1))
+        start, end = (0, 0) if trial % 3 else (int(rng.integers(0, 40)), int(rng.integers(40, 200)))
+        s = settings(1, 1, trial & 1, (trial >> 1) & 1, dev=1.2, cutoff=6.0, pitch=-7.25, start=start, end=end)
+        want = O.generate_frames(times, vals, s)
+        st = b.prepare_events_device([(times, vals)], _to_g(g, s))
+        b.generate_frames_device(st)
+        import torch
+        torch.cuda.synchronize()
+        got = st["frames"].cpu().numpy()[:want.shape[0]]
+        assert int(st["nframes_generated"].cpu().numpy()[0]) == want.shape[0]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), trial
+
+
+@pytest.mark.gpu
 def test_gpu_ragged_batch_events_to_pcm(g):
     """Event lists -> frames -> PCM without leaving the device: the generated frames equal the oracle's bit for
     bit, and the tube driven by them produces the same bits as the tube driven by uploaded frames."""
