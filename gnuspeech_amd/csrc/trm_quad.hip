@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             }
             // never more than kRowBufs blocks past the first one the convert wave still has to copy (looked up only
             // when a block is due: once per block)
-            if (rowBlk < cvtBlocks && src_position(kBase + rowBlk * kCvtCols, inc) - nBase <= step * kQB + 4u &&
+            if (TRM_ABL_CVT != 4 && rowBlk < cvtBlocks && src_position(kBase + rowBlk * kCvtCols, inc) - nBase <= step * kQB + 4u &&
                 rowBlk < __builtin_amdgcn_readfirstlane(sRowSync[0]) + kRowBufs) {
                 const uint32_t k = kBase + rowBlk * kCvtCols + ((uint32_t)lane >> 1);
                 const uint32_t off = (src_position(k, inc) - nBase + (kQLead - (kSrcWindow - 1))) & 3u;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         const uint32_t creditCap = (capPairs > 2u ? capPairs : 2u) << 16;   // two pairs per step at speech rates (earn ~ 1.1)
         uint32_t credit = 0;
         auto do_pair = [&]() {
-#if TRM_ABL_CVT == 3      /* (timing experiments: 3 = the converter's control flow only) */
+#if TRM_ABL_CVT == 3 || TRM_ABL_CVT == 4     /* (timing experiments: 3 = the converter's control flow only; 4 = and no row staging) */
             if (++pr == 4) { pr = 0; blk++; needBegin = blk < nBlocks; }
             return;
 #endif
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             if (credit > creditCap) credit = creditCap;     // a ready block is spread over the next steps, not done in a burst
             // (the two sync words are touched once per block: when a block has to begin)
             auto try_begin = [&]() {
-                if (blk < __builtin_amdgcn_readfirstlane(sRowSync[1])) {
+                if (TRM_ABL_CVT == 4 || blk < __builtin_amdgcn_readfirstlane(sRowSync[1])) {
                     begin_block();
                     needBegin = false;
                     if (lane == 0) sRowSync[0] = blk + 1;       // this block's rows are in registers now
