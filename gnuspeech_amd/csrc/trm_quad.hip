@@ -23,6 +23,9 @@
 #ifndef TRM_ABL_CVT
 #define TRM_ABL_CVT 0
 #endif
+#ifndef TRM_SCANS_IN_OSC
+#define TRM_SCANS_IN_OSC 1     /* the band-pass and throat scans run in the oscillator wave (0: in the area / mix waves) */
+#endif
 
 namespace trm {
 
@@ -116,6 +119,65 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     }
     __syncthreads();
 
+    // The two recurrences that only FEED the tube (frication band-pass, throat low-pass: nothing of the tube's state
+    // enters them) run in a feed-forward wave, serially over a voice's four slots: slot s's output is slot s+1's y1
+    // and slot s+2's y2; what wraps around belongs to the next block.  A lane's evaluation is final from its own turn
+    // on (its inputs no longer change), so the value of the last turn is everyone's.
+    struct ScanState { float by1, by2, ny1, ny2, prevSig, thY, thNext; };
+    auto scans_restore = [&](ScanState &Z, bool bandpass, bool throat) {
+        Z.by1 = Z.by2 = Z.ny1 = Z.ny2 = Z.prevSig = Z.thY = Z.thNext = 0.0f;
+        if (streaming && !sFirst) {
+            if (bandpass) {     // st[4], st[5] = the band-pass outputs of positions -2, -1; st[6], st[7] = its inputs there
+                Z.by1 = st[5];                                  // slot 0's y1
+                Z.by2 = part == 0 ? st[4] : st[5];              // slot 0's y2, slot 1's y2
+                Z.prevSig = part == 2 ? st[6] : st[7];          // slots 2, 3 of the "previous block"
+            }
+            if (throat) Z.thY = st[2];
+        }
+    };
+    // band-pass (TRMFilters.m:19-29) of block `blk`: input sX.y (mix) and coefficients (fric wave) are in LDS
+    auto bandpass_scan = [&](ScanState &Z, uint32_t blk) {
+        const int b2 = blk % kQBufs;
+        float *const xr = reinterpret_cast<float *>(&sX[(b2 * kQB + part) * kXPitch + vq]);
+        const float sig = xr[1];
+        const float4 bp = sBP[((b2 * 2) * kQB + part) * kXPitch + vq];
+        const float X = q_take<0, kPart2 | kPart3>(sig, Z.prevSig);         // slots 0, 1 look into the previous block
+        const float x2 = q_take<2, kPartAll>(X, X);
+        float f = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kQB; t++) {
+            f = bandpass_eval<float>(bp.x, bp.y, bp.z, sig, x2, Z.by1, Z.by2);
+            if (t == 0) { Z.by1 = q_take<1, kPart1>(Z.by1, f); Z.by2 = q_take<2, kPart2>(Z.by2, f); }
+            if (t == 1) { Z.by1 = q_take<1, kPart2>(Z.by1, f); Z.by2 = q_take<2, kPart3>(Z.by2, f); }
+            if (t == 2) { Z.by1 = q_take<1, kPart3>(Z.by1, f); Z.ny2 = q_take<2, kPart0>(Z.ny2, f); }
+            if (t == 3) { Z.ny1 = q_take<1, kPart0>(Z.ny1, f); Z.ny2 = q_take<2, kPart1>(Z.ny2, f); }
+        }
+        Z.by1 = q_take<0, kPart0>(Z.by1, Z.ny1);
+        Z.by2 = q_take<0, kPart0 | kPart1>(Z.by2, Z.ny2);
+        Z.prevSig = sig;
+        xr[1] = f;
+        if (streaming) {
+            const uint32_t n = blk * kQB + (uint32_t)part;
+            if (n + 2u == ntubeLane) { st[4] = f; st[6] = sig; }
+            if (n + 1u == ntubeLane) { st[5] = f; st[7] = sig; }
+        }
+    };
+    // throat low-pass (:341, TRMFilters.m:72-77) over this lane's input `thr` of sample m
+    auto throat_scan = [&](ScanState &Z, float thr, uint32_t m) {
+        float ty = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kQB; t++) {
+            ty = throat_eval<float>(C, thr, Z.thY);
+            if (t == 0) Z.thY = q_take<1, kPart1>(Z.thY, ty);
+            if (t == 1) Z.thY = q_take<1, kPart2>(Z.thY, ty);
+            if (t == 2) Z.thY = q_take<1, kPart3>(Z.thY, ty);
+            if (t == 3) Z.thNext = q_take<1, kPart0>(Z.thNext, ty);
+        }
+        Z.thY = q_take<0, kPart0>(Z.thY, Z.thNext);
+        if (streaming && m + 1u == ntubeLane) st[2] = ty;
+        return ty;
+    };
+
 #ifdef TRM_ABL_SKIP      // timing experiments only (tools/bench_variants.sh): the masked roles keep the barriers and do nothing
     if ((TRM_ABL_SKIP >> role) & 1) {
         for (uint32_t step = 0; step < nSteps; step++) step_barrier();
@@ -137,9 +199,19 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             osc_slot_setup(T, C, prev, cur, (int)j);
         }
         float2 *const ring = &sO[vq * kOStride];
+        ScanState Z;
+        scans_restore(Z, TRM_SCANS_IN_OSC, TRM_SCANS_IN_OSC);
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
+            if (TRM_SCANS_IN_OSC && step >= 2 && (step - 2) * kQB < nTotal) {
+                // block i-2: the mix wave's {sig, thr} and the coefficient wave's band-pass were written during step i-1;
+                // the tube wave reads the results from step i+1 on
+                const uint32_t blk = step - 2;
+                bandpass_scan(Z, blk);
+                float *const xr = reinterpret_cast<float *>(&sX[((blk % kQBufs) * kQB + part) * kXPitch + vq]);
+                xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
+            }
             if (step * kQB < nTotal) {
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
                     j -= CP;
@@ -211,8 +283,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // steps before the convert wave can begin the block.  Two words in LDS make that independent of timing:
         // sRowSync[1] = blocks staged (the convert wave begins no block beyond it), sRowSync[0] = the first block
         // whose rows the convert wave has not copied yet (buffer B % 3 is not rewritten before).
-        float thY = 0.0f, thNext = 0.0f;      // throat memory as seen by this lane's slot; slot 0's for the next block
-        if (streaming && !sFirst) thY = st[2];
+        ScanState Z;
+        scans_restore(Z, false, !TRM_SCANS_IN_OSC);
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
         float4 rq[4];
@@ -269,19 +341,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const float pulse = acc0.x + acc0.y;
                 const float2 a = sA[buf * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
-                // throat low-pass (:341, TRMFilters.m:72-77): nothing of the tube enters it, so it runs here, serially
-                // over the voice's four slots (slot s hands its output to slot s+1, slot 3 to the next block's slot 0)
-                float ty = 0.0f;
-#pragma unroll
-                for (int t = 0; t < kQB; t++) {      // a lane's value is final from its own turn on: its input no longer changes
-                    ty = throat_eval<float>(C, E.thr, thY);
-                    if (t == 0) thY = q_take<1, kPart1>(thY, ty);
-                    if (t == 1) thY = q_take<1, kPart2>(thY, ty);
-                    if (t == 2) thY = q_take<1, kPart3>(thY, ty);
-                    if (t == 3) thNext = q_take<1, kPart0>(thNext, ty);
-                }
-                thY = q_take<0, kPart0>(thY, thNext);
-                if (streaming && m + 1u == ntubeLane) st[2] = ty;
+#if TRM_SCANS_IN_OSC
+                const float ty = E.thr;         // (raw: the oscillator wave turns it into the throat output two steps on)
+#else
+                const float ty = throat_scan(Z, E.thr, m);
+#endif
                 sX[(xbuf * kQB + part) * kXPitch + vq] = make_float4(E.gin, E.sig, ty, 0.0f);
             }
             STAMP_MID
@@ -295,15 +359,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // Two waves share the stage by FUNCTION (both are stateless in time): role 2 turns radii and velum into
         // scattering coefficients, role 3 turns the frication tracks into taps and the band-pass.
         const bool area = role == 2;
-        // (area wave) frication band-pass memory as seen by this lane's slot, and what slots 0 / 1 start the
-        // next block with
-        float by1 = 0.0f, by2 = 0.0f, ny1 = 0.0f, ny2 = 0.0f, prevSig = 0.0f;
-        if (area && streaming && !sFirst) {
-            // st[4], st[5] = the band-pass outputs of positions -2, -1; st[6], st[7] = its inputs there
-            by1 = st[5];                                    // slot 0's y1
-            by2 = part == 0 ? st[4] : st[5];                // slot 0's y2, slot 1's y2
-            prevSig = part == 2 ? st[6] : st[7];            // slots 2, 3 of the "previous block"
-        }
+        ScanState Z;
+        scans_restore(Z, area && !TRM_SCANS_IN_OSC, false);
         CoefTrack T;
         float prev[16], cur[16], nxt[16];
         uint32_t per = 0, j = (uint32_t)part;
@@ -345,37 +402,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 }
                 j += kQB;
             }
-            if (area && step >= 2 && (step - 2) * kQB < nTotal) {
-                // Frication band-pass (TRMFilters.m:19-29) of block i-2: its input (mix, step i-1) and its
-                // coefficients (the other coefficient wave, step i-1) are in LDS; nothing of the tube enters it.
-                // Serial over the voice's four slots: slot s's output is slot s+1's y1 and slot s+2's y2; what
-                // wraps around belongs to the next block.  A lane's evaluation is final from its own turn on
-                // (its inputs no longer change), so the value of the last turn is everyone's.
-                const int b2 = (step - 2) % kQBufs;
-                float *const xr = reinterpret_cast<float *>(&sX[(b2 * kQB + part) * kXPitch + vq]);
-                const float sig = xr[1];
-                const float4 bp = sBP[((b2 * 2) * kQB + part) * kXPitch + vq];
-                const float X = q_take<0, kPart2 | kPart3>(sig, prevSig);       // slots 0, 1 look into the previous block
-                const float x2 = q_take<2, kPartAll>(X, X);
-                float f = 0.0f;
-#pragma unroll
-                for (int t = 0; t < kQB; t++) {
-                    f = bandpass_eval<float>(bp.x, bp.y, bp.z, sig, x2, by1, by2);
-                    if (t == 0) { by1 = q_take<1, kPart1>(by1, f); by2 = q_take<2, kPart2>(by2, f); }
-                    if (t == 1) { by1 = q_take<1, kPart2>(by1, f); by2 = q_take<2, kPart3>(by2, f); }
-                    if (t == 2) { by1 = q_take<1, kPart3>(by1, f); ny2 = q_take<2, kPart0>(ny2, f); }
-                    if (t == 3) { ny1 = q_take<1, kPart0>(ny1, f); ny2 = q_take<2, kPart1>(ny2, f); }
-                }
-                by1 = q_take<0, kPart0>(by1, ny1);
-                by2 = q_take<0, kPart0 | kPart1>(by2, ny2);
-                prevSig = sig;
-                xr[1] = f;
-                if (streaming) {
-                    const uint32_t n = (step - 2) * kQB + (uint32_t)part;
-                    if (n + 2u == ntubeLane) { st[4] = f; st[6] = sig; }
-                    if (n + 1u == ntubeLane) { st[5] = f; st[7] = sig; }
-                }
-            }
+            if (!TRM_SCANS_IN_OSC && area && step >= 2 && (step - 2) * kQB < nTotal) bandpass_scan(Z, step - 2);
             STAMP_MID
             step_barrier();
             STAMP_END
