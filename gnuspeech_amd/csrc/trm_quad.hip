@@ -30,7 +30,11 @@
 namespace trm {
 
 constexpr int kQV = 16;              // voices per workgroup
-constexpr int kQB = kSlots;          // tube samples per step = time slots per voice
+constexpr int kQB = kSlots;          // tube samples per block = time slots per voice
+constexpr int kSub = 2;              // blocks per pipeline step: the feed-forward waves run two INDEPENDENT blocks per
+                                     // step (their instruction streams interleave and hide each other's latencies), the
+                                     // tube wave 8 samples in a row; half as many barriers
+constexpr int kStepN = kQB * kSub;   // tube samples per step
 constexpr int kQRoles = 6;           // osc, mix, coef x2 (area | frication), tube, convert
 constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
 constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
@@ -38,8 +42,9 @@ constexpr int kOStride = kORing + kOMirror + 4;   // + 32 bytes: a row of lanes 
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
-constexpr int kQBufs = 4;           // mix/coef -> tube hand-off buffers: block b lives in buffer b % 4 (the tube stage reads block
-                                     // i-4 and the head of block i-3, the band-pass works on block i-2, block i-1 is being written)
+constexpr int kQBufs = 4 * kSub;    // mix/coef -> tube hand-off buffers: block b lives in buffer b % 8 (at step i the tube stage
+                                     // reads the blocks of step i-4 and the head of step i-3's, the band-pass works on step i-2's,
+                                     // step i-1's are being written)
 constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS: block B in buffer B % 3
 constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes apart, so that 16 lanes reading 16 rows hit 16 bank groups
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
@@ -51,7 +56,7 @@ template <bool kStream>
 __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const C, const TubeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float2 sO[kQV * kOStride];            // osc -> mix: oscillator reads
-    __shared__ __attribute__((aligned(16))) float2 sA[2 * kWave];                 // osc -> mix: {ax, ah1}
+    __shared__ __attribute__((aligned(16))) float2 sA[2 * kSub * kWave];          // osc -> mix: {ax, ah1} per (block & 3, lane)
     __shared__ __attribute__((aligned(16))) float4 sX[kQBufs * kQB * kXPitch];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
     __shared__ __attribute__((aligned(16))) float4 sBP[kQBufs * 2 * kQB * kXPitch];            // coef -> tube: SharedRecord [buf][half][slot][voice]
     __shared__ __attribute__((aligned(16))) float4 sK[kQBufs * kQB * kKPitch];     // coef -> tube: part records
@@ -94,8 +99,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     float *const st = streaming ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
     // tube samples the tube stage produces: the utterance (chunk), then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93)
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + (sLast ? 2u * (uint32_t)C.padSize : 0u) : 0;
-    // the tube stage steps block i-4 at step i; the convert wave finishes what is queued after the last barrier
-    const uint32_t nSteps = nTotal > 0 ? (nTotal + kQB - 1) / kQB + 5 : 0;
+    // the tube stage steps the blocks of step i-4 at step i; the convert wave finishes what is queued after the last barrier
+    const uint32_t nSteps = nTotal > 0 ? (nTotal + kStepN - 1) / kStepN + 5 : 0;
     const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
@@ -204,15 +209,21 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (TRM_SCANS_IN_OSC && step >= 2 && (step - 2) * kQB < nTotal) {
-                // block i-2: the mix wave's {sig, thr} and the coefficient wave's band-pass were written during step i-1;
-                // the tube wave reads the results from step i+1 on
-                const uint32_t blk = step - 2;
-                bandpass_scan(Z, blk);
-                float *const xr = reinterpret_cast<float *>(&sX[((blk % kQBufs) * kQB + part) * kXPitch + vq]);
-                xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
+#pragma unroll
+            for (int u = 0; u < kSub; u++) {
+                // the blocks of step i-2: the mix wave's {sig, thr} and the coefficient wave's band-pass were written
+                // during step i-1; the tube wave reads the results from step i+1 on
+                const uint32_t blk = (step - 2) * kSub + u;
+                if (TRM_SCANS_IN_OSC && step >= 2 && blk * kQB < nTotal) {
+                    bandpass_scan(Z, blk);
+                    float *const xr = reinterpret_cast<float *>(&sX[((blk % kQBufs) * kQB + part) * kXPitch + vq]);
+                    xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
+                }
             }
-            if (step * kQB < nTotal) {
+#pragma unroll
+            for (int u = 0; u < kSub; u++) {
+              const uint32_t oblk = step * kSub + u;
+              if (oblk * kQB < nTotal) {
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
                     j -= CP;
                     per++;
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 pre += q_take<2, kPart2 | kPart3>(0.0, pre);
                 const double end = P + pre;
                 const double pos2 = osc_wrap(end), pos1 = osc_wrap(end - oinc);
-                if (streaming && step * kQB + (uint32_t)part + 1u == ntubeLane) *reinterpret_cast<double *>(st) = pos2;   // the chunk's last sample
+                if (streaming && oblk * kQB + (uint32_t)part + 1u == ntubeLane) *reinterpret_cast<double *>(st) = pos2;   // the chunk's last sample
                 double tot = pre;                                // slot 3's prefix = the block's advance
                 tot = q_take<1, kPart0>(tot, pre);
                 tot = q_take<2, kPart1>(tot, pre);
@@ -242,10 +253,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 T.f0 *= T.f0Step;
                 T.axGeo *= T.axStep;
                 j += kQB;
-                const uint32_t slot = (step * kQB + (uint32_t)part) & (kORing - 1);
+                const uint32_t slot = (oblk * kQB + (uint32_t)part) & (kORing - 1);
                 ring[slot] = make_float2(wa, wb);
                 if (slot < (uint32_t)kOMirror) ring[slot + kORing] = make_float2(wa, wb);
-                sA[(step & 1) * kWave + lane] = make_float2((float)axd, ah1);
+                sA[(oblk & 3) * kWave + lane] = make_float2((float)axd, ah1);
+              }
             }
             STAMP_MID
             step_barrier();
@@ -294,26 +306,32 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (rowsInFlight) {
+            auto rows_to_lds = [&]() {
                 float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) % kRowBufs) * (kCvtCols * kRowPitch) + (lane >> 1) * kRowPitch + (lane & 1) * 16]);
                 for (int q = 0; q < 4; q++) dst[q] = rq[q];
                 rowsInFlight = false;
                 if (lane == 0) sRowSync[1] = rowBlk;            // blocks 0 .. rowBlk-1 are in LDS after this step's barrier
-            }
+            };
+            if (rowsInFlight) rows_to_lds();
             // never more than kRowBufs blocks past the first one the convert wave still has to copy (looked up only
-            // when a block is due: once per block)
-            if (TRM_ABL_CVT != 4 && rowBlk < cvtBlocks && src_position(kBase + rowBlk * kCvtCols, inc) - nBase <= step * kQB + 4u &&
-                rowBlk < __builtin_amdgcn_readfirstlane(sRowSync[0]) + kRowBufs) {
-                const uint32_t k = kBase + rowBlk * kCvtCols + ((uint32_t)lane >> 1);
-                const uint32_t off = (src_position(k, inc) - nBase + (kQLead - (kSrcWindow - 1))) & 3u;
-                const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off + (lane & 1) * 16;
-                for (int q = 0; q < 4; q++) rq[q] = make_float4(pc[4 * q], pc[4 * q + 1], pc[4 * q + 2], pc[4 * q + 3]);
-                rowsInFlight = true;
-                rowBlk++;
+            // when a block is due: about once per block).  Up to two blocks per step (rate ratios above 4).
+            for (int r = 0; r < 2; r++) {
+                if (TRM_ABL_CVT != 4 && rowBlk < cvtBlocks && src_position(kBase + rowBlk * kCvtCols, inc) - nBase <= step * kStepN + 4u &&
+                    rowBlk < __builtin_amdgcn_readfirstlane(sRowSync[0]) + kRowBufs) {
+                    if (rowsInFlight) rows_to_lds();            // (a second block in the same step: its predecessor's loads are waited for here)
+                    const uint32_t k = kBase + rowBlk * kCvtCols + ((uint32_t)lane >> 1);
+                    const uint32_t off = (src_position(k, inc) - nBase + (kQLead - (kSrcWindow - 1))) & 3u;
+                    const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off + (lane & 1) * 16;
+                    for (int q = 0; q < 4; q++) rq[q] = make_float4(pc[4 * q], pc[4 * q + 1], pc[4 * q + 2], pc[4 * q + 3]);
+                    rowsInFlight = true;
+                    rowBlk++;
+                }
             }
-            if (step >= 1 && (step - 1) * kQB < nTotal) {
-                const uint32_t blk = step - 1;
-                const int buf = blk & 1, xbuf = blk % kQBufs;
+#pragma unroll
+            for (int u = 0; u < kSub; u++) {
+              const uint32_t blk = (step - 1) * kSub + u;
+              if (step >= 1 && blk * kQB < nTotal) {
+                const int buf = blk & 3, xbuf = blk % kQBufs;
                 const uint32_t n0 = blk * kQB;
                 if ((n0 & (kNoiseHalf - 1)) == 0 && n0 > 0) {
                     // entering a noise half: it was requested one half ago; refill the other half
@@ -347,6 +365,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const float ty = throat_scan(Z, E.thr, m);
 #endif
                 sX[(xbuf * kQB + part) * kXPitch + vq] = make_float4(E.gin, E.sig, ty, 0.0f);
+              }
             }
             STAMP_MID
             step_barrier();
@@ -373,8 +392,11 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 1 && (step - 1) * kQB < nTotal) {
-                const int buf = (step - 1) % kQBufs;
+#pragma unroll
+            for (int u = 0; u < kSub; u++) {
+              const uint32_t blk = (step - 1) * kSub + u;
+              if (step >= 1 && blk * kQB < nTotal) {
+                const int buf = blk % kQBufs;
                 if (j >= CP) {
                     j -= CP;
                     per++;
@@ -401,8 +423,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     sBP[((buf * 2) * kQB + part) * kXPitch + vq] = make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f);
                 }
                 j += kQB;
+              }
             }
-            if (!TRM_SCANS_IN_OSC && area && step >= 2 && (step - 2) * kQB < nTotal) bandpass_scan(Z, step - 2);
+            for (int u = 0; u < kSub; u++)
+                if (!TRM_SCANS_IN_OSC && area && step >= 2 && ((step - 2) * kSub + u) * kQB < nTotal) bandpass_scan(Z, (step - 2) * kSub + u);
             STAMP_MID
             step_barrier();
             STAMP_END
@@ -446,16 +470,18 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                                          v2f_t{r.k4.x, r.k4.y}, v2f_t{r.k4.z, r.k4.w}, v2f_t{r.t4.x, r.t4.y},
                                          v2f_t{r.t4.z, r.t4.w});
         };
-        // Block i-4 at step i (its band-pass output was written during step i-2).  Its first sample's inputs were
-        // fetched during step i-1, the other three are fetched now and land behind the first sample's
-        // arithmetic, and the head of block i-3 is fetched behind the last: no LDS latency is exposed.
+        // The blocks of step i-4 at step i (their band-pass output was written during step i-2).  A block's first
+        // sample's inputs are fetched behind the last sample of the block before it (for the step's first block:
+        // during step i-1), the other three land behind the first sample's arithmetic: no LDS latency is exposed.
         In head;
         head.x = head.e4 = head.k4 = head.t4 = make_float4(0.f, 0.f, 0.f, 0.f);
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            if (step >= 4 && (step - 4) * kQB < nTotal) {
-                const uint32_t blk = step - 4;
+#pragma unroll
+            for (int u = 0; u < kSub; u++) {
+              const uint32_t blk = (step - 4) * kSub + u;
+              if (step >= 4 && blk * kQB < nTotal) {
                 const uint32_t n0 = blk * kQB;
                 const In i1 = load_in(blk, 1), i2 = load_in(blk, 2), i3 = load_in(blk, 3);
                 float y[kQB];
@@ -487,9 +513,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                             if (n0 + s < lim) tubeOut[n0 + s] = y[s];
                     }
                 }
-            } else if (step == 3 && nTotal > 0) {
-                head = load_in(0, 0);
+              }
             }
+            if (step == 3 && nTotal > 0) head = load_in(0, 0);
             STAMP_MID
             step_barrier();
             STAMP_END
@@ -550,7 +576,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         typedef __attribute__((address_space(3))) float *LdsFloatPtr;
         // metering (16.16 row pairs per step): a step's kQB tube samples turn into kQB * 2^16/inc outputs per
         // voice = that / 32 blocks of 4 row pairs
-        const uint32_t earn = (uint32_t)(((uint64_t)kQB << 32) / inc / 8) + 2048;
+        const uint32_t earn = (uint32_t)(((uint64_t)kStepN << 32) / inc / 8) + 2048;
         // the cap must leave room to catch up after waiting for a block (a cap of about `earn` loses credit while
         // it waits and the wave falls behind until the ring laps it: seen at a 30 cm tube, ratio 3.8)
         const uint32_t capPairs = (earn + 0x18000u) >> 16;                  // floor(earn + 1.5)
@@ -618,8 +644,8 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
-            // visible after the previous barrier: tube samples n < (step-4)*kQB
-            const uint32_t ready = step >= 4 ? (step - 4) * kQB : 0;
+            // visible after the previous barrier: tube samples n < (step-4)*kStepN
+            const uint32_t ready = step >= 4 ? (step - 4) * kStepN : 0;
             credit += earn;
             if (credit > creditCap) credit = creditCap;     // a ready block is spread over the next steps, not done in a burst
             // (the two sync words are touched once per block: when a block has to begin)
