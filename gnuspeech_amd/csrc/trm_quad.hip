@@ -24,7 +24,7 @@
 #define TRM_ABL_CVT 0
 #endif
 #ifndef TRM_SCANS_IN_OSC
-#define TRM_SCANS_IN_OSC 1     /* the band-pass and throat scans run in the oscillator wave (0: in the area / mix waves) */
+#define TRM_SCANS_IN_OSC 0     /* 1: the band-pass and throat scans run in the oscillator wave; 0: in the area / mix waves */
 #endif
 
 namespace trm {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     // others are paired so that the SIMDs carry about the same work (tools/stage_profile.py)
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifndef TRM_QROLE_PERM
-#define TRM_QROLE_PERM 5, 1, 0, 4, 2, 3      /* convert mix osc tube | coef-area coef-fric */
+#define TRM_QROLE_PERM 1, 0, 5, 4, 2, 3      /* mix osc convert tube | coef-area coef-fric */
 #endif
     const int rolePerm[kQRoles] = {TRM_QROLE_PERM};
     int role = 0;
