@@ -166,10 +166,10 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     b->c = c;
     b->d = d;
     b->device = device;
-    // The four-lane form wins while its workgroups (16 voices each) get a CU each: one of them already keeps
-    // the CU's four SIMDs busy, so a second resident workgroup only doubles the time (measured: 4096 voices
-    // 3.6 ms, 8192 voices 7.4 ms vs 6.9 ms one voice per lane).
-    b->wideThreshold = 16u * (uint32_t)prop.multiProcessorCount + 1u;
+    // The four-lane form wins up to two rounds of one workgroup (16 voices) per CU: one workgroup keeps a CU's
+    // four SIMDs busy, so more voices run in rounds (measured on 256 CUs: 4096 voices 3.1 ms, 8192 6.2 ms, 12288
+    // 9.0 ms) while the one-voice-per-lane form takes 7.1 ms for anything up to 16384 (profiles/sweep_forms_r01.txt).
+    b->wideThreshold = 2u * 16u * (uint32_t)prop.multiProcessorCount + 1u;
     std::vector<float> rows, sine;
     trm::build_src_rows(rows);
     trm::build_sine_table(sine);

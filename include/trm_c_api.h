@@ -276,7 +276,7 @@ int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_
 /* Kernel form of the synthesis launch.  Both forms compute the same samples (same arithmetic per value);
  * they differ in how a voice is laid out on the machine:
  *   TRM_KERNEL_WIDE  one voice per lane, 64 voices per workgroup: highest throughput once the batch fills
- *                    the chip (>= ~32 k voices);
+ *                    the chip (AUTO: above 32 voices per CU, 8192 on MI355X);
  *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: lowest latency for smaller batches.
  * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad
  * overrides AUTO (diagnostics).  No reference counterpart: the reference runs one tube per thread. */
