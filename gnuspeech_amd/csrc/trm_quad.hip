@@ -23,8 +23,13 @@
 #ifndef TRM_ABL_CVT
 #define TRM_ABL_CVT 0
 #endif
-#ifndef TRM_SCANS_IN_OSC
-#define TRM_SCANS_IN_OSC 0     /* 1: the band-pass and throat scans run in the oscillator wave; 0: in the area / mix waves */
+/* where the two scans that feed the tube run: the band-pass in the oscillator wave (1) or the area wave (0), the
+   throat low-pass in the oscillator wave (1) or the mix wave (0) */
+#ifndef TRM_BP_IN_OSC
+#define TRM_BP_IN_OSC 0
+#endif
+#ifndef TRM_THROAT_IN_OSC
+#define TRM_THROAT_IN_OSC 1
 #endif
 
 namespace trm {
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         }
         float2 *const ring = &sO[vq * kOStride];
         ScanState Z;
-        scans_restore(Z, TRM_SCANS_IN_OSC, TRM_SCANS_IN_OSC);
+        scans_restore(Z, TRM_BP_IN_OSC, TRM_THROAT_IN_OSC);
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
@@ -214,10 +219,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 // the blocks of step i-2: the mix wave's {sig, thr} and the coefficient wave's band-pass were written
                 // during step i-1; the tube wave reads the results from step i+1 on
                 const uint32_t blk = (step - 2) * kSub + u;
-                if (TRM_SCANS_IN_OSC && step >= 2 && blk * kQB < nTotal) {
-                    bandpass_scan(Z, blk);
-                    float *const xr = reinterpret_cast<float *>(&sX[((blk % kQBufs) * kQB + part) * kXPitch + vq]);
-                    xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
+                if ((TRM_BP_IN_OSC || TRM_THROAT_IN_OSC) && step >= 2 && blk * kQB < nTotal) {
+                    if (TRM_BP_IN_OSC) bandpass_scan(Z, blk);
+                    if (TRM_THROAT_IN_OSC) {
+                        float *const xr = reinterpret_cast<float *>(&sX[((blk % kQBufs) * kQB + part) * kXPitch + vq]);
+                        xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
+                    }
                 }
             }
 #pragma unroll
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // sRowSync[1] = blocks staged (the convert wave begins no block beyond it), sRowSync[0] = the first block
         // whose rows the convert wave has not copied yet (buffer B % 3 is not rewritten before).
         ScanState Z;
-        scans_restore(Z, false, !TRM_SCANS_IN_OSC);
+        scans_restore(Z, false, !TRM_THROAT_IN_OSC);
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
         float4 rq[4];
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const float pulse = acc0.x + acc0.y;
                 const float2 a = sA[buf * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
-#if TRM_SCANS_IN_OSC
+#if TRM_THROAT_IN_OSC
                 const float ty = E.thr;         // (raw: the oscillator wave turns it into the throat output two steps on)
 #else
                 const float ty = throat_scan(Z, E.thr, m);
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         // scattering coefficients, role 3 turns the frication tracks into taps and the band-pass.
         const bool area = role == 2;
         ScanState Z;
-        scans_restore(Z, area && !TRM_SCANS_IN_OSC, false);
+        scans_restore(Z, area && !TRM_BP_IN_OSC, false);
         CoefTrack T;
         float prev[16], cur[16], nxt[16];
         uint32_t per = 0, j = (uint32_t)part;
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
               }
             }
             for (int u = 0; u < kSub; u++)
-                if (!TRM_SCANS_IN_OSC && area && step >= 2 && ((step - 2) * kSub + u) * kQB < nTotal) bandpass_scan(Z, (step - 2) * kSub + u);
+                if (!TRM_BP_IN_OSC && area && step >= 2 && ((step - 2) * kSub + u) * kQB < nTotal) bandpass_scan(Z, (step - 2) * kSub + u);
             STAMP_MID
             step_barrier();
             STAMP_END
