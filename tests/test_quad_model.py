@@ -1,0 +1,58 @@
+"""Host model of the kernels' arithmetic (tests/_emul/trm_emul.cc: gnuspeech_amd/csrc/trm_lane.h and trm_quad.h
+compiled for the CPU, TEST INFRASTRUCTURE).  Without a GPU this checks
+  * that the four-lane tube step (two-wide junction rounds, cross-part moves, both ends in one part) reproduces the
+    one-voice-per-lane tube_step BIT FOR BIT on random states and coefficients (the data movement is exact), and
+  * that both formulations (fp32 signal path, closed-form tracks, prefix-sum oscillator phase, direct-form FIR)
+    meet the parity tolerance against the oracle on the reference fixtures."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_io
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "_emul", "trm_emul.cc")
+LIB = os.path.join(ROOT, "tests", "_emul", "libtrm_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    csrc = os.path.join(ROOT, "gnuspeech_amd", "csrc")
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("trm_lane.h", "trm_quad.h", "trm_setup.cc", "trm_setup.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-o", LIB, SRC,
+                               os.path.join(csrc, "trm_setup.cc"), "-lm"])
+    E = C.CDLL(LIB)
+    sig = [C.POINTER(O.InputParams), C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t,
+           C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    E.trm_emul_synthesize.argtypes = sig
+    E.trm_emul_synthesize_quad.argtypes = sig
+    E.trm_emul_quad_selfcheck.argtypes = [C.POINTER(O.InputParams), C.c_int, C.c_uint]
+    return E
+
+
+def test_four_lane_step_equals_one_lane_step_bit_for_bit(emul):
+    p = golden_io.load("gnuspeech_window_44k")["params"]
+    for seed in (1, 2, 3):
+        assert emul.trm_emul_quad_selfcheck(C.byref(p), 20000, seed) == 0
+
+
+@pytest.mark.parametrize("name", ["tract_vowel_1s", "gnuspeech_input_22k", "sine_nomod", "frication_sweep", "female_15cm_stereo"])
+def test_both_formulations_against_oracle(emul, name):
+    g = golden_io.load(name)
+    p, fr = g["params"], np.ascontiguousarray(g["frames"], dtype=np.float32)
+    o = O.synthesize(p, fr.astype(np.float64))
+    for fn in (emul.trm_emul_synthesize, emul.trm_emul_synthesize_quad):
+        cap = len(fr) * 700 + 2000
+        out = np.zeros(cap, dtype=np.float32)
+        n, m = C.c_uint32(), C.c_float()
+        assert fn(C.byref(p), fr.ctypes.data_as(C.POINTER(C.c_float)), len(fr), out.ctypes.data_as(C.POINTER(C.c_float)), cap,
+                  C.byref(n), C.byref(m), None) == 0
+        assert n.value == o["numberSamples"]
+        e = (out[:n.value].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
+        assert float(np.sqrt(np.mean(e * e))) <= 1e-5
+        assert abs(m.value - o["maximumSampleValue"]) / o["maximumSampleValue"] < 2e-4
