@@ -8,10 +8,12 @@
 //                    oscillator phase is a 4-wide prefix sum, the FIR runs in direct form over an LDS ring)
 //   tube             lanes = 4 parts of the tube, junction values crossing a part boundary move by DPP
 //   convert          lane = output time, as in the wide kernel (rows of 32 outputs x 2 voices)
-// so one pass of the instruction streams advances 4 tube samples and 256 workgroups cover 4096 voices.
-// One barrier per step of kQB = 4 tube samples; osc works on block i, mix and coef on block i-1, tube on
-// block i-4 (the band-pass and throat recurrences, which only FEED the tube, run in the coefficient and mix
-// waves on blocks i-2 and i-1), convert on whatever is complete, metered.
+// so one pass of the instruction streams advances 4 tube samples (a "block") and 256 workgroups cover 4096
+// voices.  One barrier per STEP of kSub = 2 blocks: the feed-forward waves run the step's two blocks as two
+// independent instruction streams (each hides the other's latencies), the tube wave 8 samples in a row.  At step i
+// osc works on the blocks of step i, mix and coef on those of step i-1, the band-pass and throat scans (recurrences
+// that only FEED the tube; they live in feed-forward waves) on those of step i-2, tube on those of step i-4,
+// convert on whatever is complete, metered.  trm_tube_kernel_q<true> is the streaming instance (state in / out).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
