@@ -34,23 +34,41 @@ class TRMBatch:
         return lib().trm_batch_samples_for_frames(self._h, int(nframes))
 
     # -------------------------------------------------------------- host buffers (incl. H2D / D2H)
-    def synthesize(self, voices):
-        """voices: list of [n_v,16] arrays (ragged allowed).  Returns (list of fp32 PCM arrays,
-        numberSamples uint32[V], maximumSampleValue float32[V])."""
+    def synthesize(self, voices, reuse_output=False):
+        """voices: list of [n_v,16] arrays (ragged allowed) or one [V,N,16] array.  Returns (list of fp32 PCM
+        arrays, numberSamples uint32[V], maximumSampleValue float32[V]).  reuse_output=True returns views into a
+        buffer this object keeps and overwrites on the next call (a fresh 700 MB numpy buffer costs more in first-
+        touch page faults than the D2H copy that fills it, profiles/host_path_r01.txt): copy what must outlive
+        the next call."""
         V = len(voices)
-        nfr = np.array([len(v) for v in voices], dtype=np.uint32)
+        if isinstance(voices, np.ndarray) and voices.ndim == 3:
+            nfr = np.full(V, voices.shape[1], dtype=np.uint32)
+            frames = np.ascontiguousarray(voices.reshape(-1, 16), dtype=np.float32)
+            if not len(frames):
+                frames = np.zeros((1, 16), dtype=np.float32)
+        else:
+            nfr = np.array([len(v) for v in voices], dtype=np.uint32)
+            frames = None
         foff = np.zeros(max(1, V), dtype=np.uint64)
         if V > 1:
             foff[1:V] = np.cumsum(nfr[:-1], dtype=np.uint64)
-        frames = np.zeros((max(1, int(nfr.sum())), 16), dtype=np.float32)
-        for v, fr in enumerate(voices):
-            if len(fr):
-                frames[int(foff[v]):int(foff[v]) + len(fr)] = np.asarray(fr, dtype=np.float32)
-        nout = np.array([self.samples_for_frames(n) for n in nfr], dtype=np.uint64)
+        if frames is None:
+            frames = np.zeros((max(1, int(nfr.sum())), 16), dtype=np.float32)
+            for v, fr in enumerate(voices):
+                if len(fr):
+                    frames[int(foff[v]):int(foff[v]) + len(fr)] = np.asarray(fr, dtype=np.float32)
+        lut = {int(n): self.samples_for_frames(int(n)) for n in np.unique(nfr)}
+        nout = np.array([lut[int(n)] for n in nfr], dtype=np.uint64)
         ooff = np.zeros(max(1, V), dtype=np.uint64)
         if V > 1:
             ooff[1:V] = np.cumsum(nout[:-1], dtype=np.uint64)
-        out = np.zeros(max(1, int(nout.sum())), dtype=np.float32)
+        total = max(1, int(nout.sum()))
+        if reuse_output:
+            if getattr(self, "_host_out", None) is None or self._host_out.size < total:
+                self._host_out = np.ones(total + total // 8, dtype=np.float32)      # ones: every page touched
+            out = self._host_out[:total]
+        else:
+            out = np.zeros(total, dtype=np.float32)
         ns = np.zeros(max(1, V), dtype=np.uint32)
         mx = np.zeros(max(1, V), dtype=np.float32)
         nfr_c = np.ascontiguousarray(nfr if V else np.zeros(1, np.uint32))

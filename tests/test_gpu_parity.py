@@ -305,6 +305,24 @@ def test_device_path_and_int16(g, form):
     assert n >= 2 and t > 0.0
 
 
+def test_host_entry_input_forms_and_kept_buffer(g, form):
+    """TRMBatch.synthesize: a [V,N,16] array == the list of its voices; the kept output buffer (reuse_output)
+    gives the same bits and is overwritten by the next call."""
+    pd = cases.monet_default_params(44100.0)
+    fr = np.ascontiguousarray(cases.config3_frames(70, nframes=25), dtype=np.float32)
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    pcm, ns, mx = b.synthesize(list(fr))
+    pcm2, ns2, mx2 = b.synthesize(fr, reuse_output=True)
+    assert np.array_equal(ns, ns2) and np.array_equal(mx, mx2)
+    for v in range(70):
+        assert np.array_equal(pcm[v], pcm2[v])
+    keep = pcm2[3].copy()
+    pcm3, ns3, _ = b.synthesize(fr[::-1].copy(), reuse_output=True)
+    assert np.array_equal(pcm3[66], keep) and pcm3[0].base is pcm2[0].base
+    pcm4, ns4, _ = b.synthesize(np.zeros((0, 5, 16), np.float32), reuse_output=True)
+    assert pcm4 == [] and len(ns4) == 0
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
