@@ -124,11 +124,17 @@ def main():
     # HBM bytes per launch from the PMC passes kept under profiles/ (collected separately: --pmc cannot be
     # combined with the timed run); only quoted when it was measured on this very workload
     traffic = None
+    valu = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
         w = tj["workload"]
         if (w["voices_per_gpu"], w["frames_per_voice"], w["kind"]) == (a.voices, nframes, a.workload):
             traffic = tj["traffic_bytes_per_launch"]
+            if b.last_kernel == "quad" and "SQ_INSTS_VALU" in tj:
+                # the bound that binds: wave64 VALU instructions (PMC, same profile) x 4 cycles on one
+                # of 256 CUs x 4 SIMD16, against this run's launch time at the 2.4 GHz peak clock
+                valu = {"insts_per_launch": tj["SQ_INSTS_VALU"], "source": "profiles/traffic_r01.json (rocprofv3 --pmc SQ_INSTS_VALU)",
+                        "frac_of_issue_slots": tj["SQ_INSTS_VALU"] * 4.0 / (avg_launch_s * 2.4e9 * 1024)}
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -144,7 +150,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": {"wide": "trm_tube_kernel", "quad": "trm_tube_kernel_q"}[b.last_kernel], "avg_launch_ms": kern_ms / max(1, launches),
-                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
                      "note": "VALU-issue bound scalar recurrence (SURVEY 8d); HBM-write fraction reported as BASELINE asks"},
     }
     if rank == 0:
