@@ -78,6 +78,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     if (lane == 0 && A.stamps) {                                                    \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8] = st_work;                    \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 1] = st_wait;                \
+        A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_ID */ \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 5] = st_long;                \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 6] = st_excess;              \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 7] = st_max;                 \
