@@ -3,7 +3,7 @@
 
 A "step" = one pass of -[TRMTubeModel synthesize] over one resident batch of synthetic control
 tracks.  N=1 workload = BASELINE.json configs[1]: 4096 static-vowel tubes x 1 s @ 44.1 kHz, fp32,
-one tube per lane.  N>1: the same per-GPU batch on every rank (weak scaling, no collective: voices
+four lanes per tube (the library picks the kernel form by batch size).  N>1: the same per-GPU batch on every rank (weak scaling, no collective: voices
 are independent), launched one rank per GPU by torch.distributed.run.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
