@@ -116,6 +116,15 @@ def test_batch_ragged_config4(g, form):
     _batch_vs_oracle(g, cases.monet_default_params(22050.0), voices)
 
 
+def test_long_utterance(g, form):
+    """80 s in one voice (20 001 frames, 1.58 M tube samples, 3.5 M outputs) beside two short ones: the 16.16 time
+    register, the noise table and the ring positions far from their start; nothing drifts."""
+    rows = cases.load_gnuspeech_rows()
+    long_voice = np.concatenate([rows] * (20001 // len(rows) + 1))[:20001]
+    worst = _batch_vs_oracle(g, cases.monet_default_params(44100.0), [long_voice, rows[:40].copy(), rows[100:131].copy()])
+    assert worst <= RMS_TOL
+
+
 def test_downsampling_batch(g, form):
     """Tube rate above the output rate (short tubes, 22.05 kHz): TRMSampleRateConverter.m:234-297 on the GPU,
     ragged voices, against the oracle."""
