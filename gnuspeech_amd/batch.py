@@ -1,4 +1,4 @@
-"""Batch front end: V independent tubes, one per GPU lane, sharing one TRMInputParameters.
+"""Batch front end: V independent tubes sharing one TRMInputParameters.
 
 torch is used only as the owner of device memory and streams (plumbing): the kernels are
 libtrm_hip.so's.  Layout in HBM:
@@ -40,6 +40,9 @@ class TRMBatch:
         buffer this object keeps and overwrites on the next call (a fresh 700 MB numpy buffer costs more in first-
         touch page faults than the D2H copy that fills it, profiles/host_path_r01.txt): copy what must outlive
         the next call."""
+        return self._synthesize_host(lib().trm_batch_synthesize_host, voices, reuse_output)
+
+    def _synthesize_host(self, entry, voices, reuse_output):
         V = len(voices)
         if isinstance(voices, np.ndarray) and voices.ndim == 3:
             nfr = np.full(V, voices.shape[1], dtype=np.uint32)
@@ -72,7 +75,7 @@ class TRMBatch:
         ns = np.zeros(max(1, V), dtype=np.uint32)
         mx = np.zeros(max(1, V), dtype=np.float32)
         nfr_c = np.ascontiguousarray(nfr if V else np.zeros(1, np.uint32))
-        check(lib().trm_batch_synthesize_host(self._h, V, frames.ctypes.data, foff.ctypes.data, nfr_c.ctypes.data,
+        check(entry(self._h, V, frames.ctypes.data, foff.ctypes.data, nfr_c.ctypes.data,
                                               out.ctypes.data, ooff.ctypes.data, ns.ctypes.data, mx.ctypes.data))
         pcm = [out[int(ooff[v]):int(ooff[v]) + int(ns[v])] for v in range(V)]
         return pcm, ns[:V], mx[:V]
@@ -191,3 +194,43 @@ class TRMBatch:
         n = C.c_uint32()
         check(lib().trm_batch_kernel_time_ms(self._h, C.byref(t), C.byref(n)))
         return t.value, n.value
+
+
+def shard_voices(nframes, nshards):
+    """Contiguous voice ranges balanced by frame count: bounds[g] .. bounds[g+1] is shard g (trm_shard_voices; what
+    trm_multi_synthesize_host uses per device, and what a one-process-per-GPU launcher can use per rank)."""
+    nfr = np.ascontiguousarray(nframes, dtype=np.uint32)
+    bounds = np.zeros(int(nshards) + 1, dtype=np.uint64)
+    assert bounds.itemsize == C.sizeof(C.c_size_t)
+    check(lib().trm_shard_voices(nfr.ctypes.data if len(nfr) else None, len(nfr), int(nshards), bounds.ctypes.data))
+    return [int(x) for x in bounds]
+
+
+class TRMMultiBatch(TRMBatch):
+    """One process, several GPUs: contiguous voice ranges per device, one host thread and stream per
+    device, no collective.  Host-buffer entry only; `devices` may repeat a device."""
+
+    def __init__(self, inputParameters, devices):
+        self._h = C.c_void_p()
+        self.inputParameters = inputParameters
+        self.devices = [int(d) for d in devices]
+        dv = (C.c_int * len(self.devices))(*self.devices)
+        check(lib().trm_multi_create(C.byref(inputParameters.c), dv, len(self.devices), C.byref(self._h)))
+        d = TrmDerived()
+        check(lib().trm_derive(C.byref(inputParameters.c), C.byref(d)))
+        self.derived = {k: getattr(d, k) for k, _ in TrmDerived._fields_}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().trm_multi_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def samples_for_frames(self, nframes):
+        return lib().trm_samples_for_frames(C.byref(self.inputParameters.c), int(nframes))
+
+    def synthesize(self, voices, reuse_output=False):
+        return self._synthesize_host(lib().trm_multi_synthesize_host, voices, reuse_output)

@@ -12,6 +12,7 @@
 
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "../../include/trm_c_api.h"
@@ -620,6 +621,112 @@ int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames,
     HIP_TRY(hipMemcpyAsync(number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return TRM_OK;
+}
+
+// ------------------------------------------------------------------ several devices from one process
+int trm_shard_voices(const uint32_t *nframes, size_t nvoices, size_t nshards, size_t *bounds)
+{
+    if (!bounds || nshards == 0 || (nvoices && !nframes)) return fail(TRM_EINVAL, "null argument / no shards");
+    // cost of a voice = its frames + 1 (a launch lasts as long as its longest voice, but the bytes moved and the
+    // lanes occupied go with the sum); boundary g sits where the running cost passes g/nshards of the total
+    uint64_t total = 0;
+    for (size_t v = 0; v < nvoices; v++) total += (uint64_t)nframes[v] + 1u;
+    bounds[0] = 0;
+    size_t v = 0;
+    uint64_t run = 0;
+    for (size_t g = 1; g < nshards; g++) {
+        const uint64_t target = (total * g + nshards / 2) / nshards;
+        while (v < nvoices && run + ((uint64_t)nframes[v] + 1u) / 2 < target) run += (uint64_t)nframes[v++] + 1u;
+        bounds[g] = v;
+    }
+    bounds[nshards] = nvoices;
+    return TRM_OK;
+}
+
+struct trm_multi {
+    std::vector<trm_batch *> b;
+};
+
+int trm_multi_create(const trm_input_params *params, const int *devices, size_t ndevices, trm_multi **out)
+{
+    if (!params || !devices || !out || ndevices == 0) return fail(TRM_EINVAL, "null argument / no devices");
+    *out = nullptr;
+    trm_multi *m = new trm_multi;
+    for (size_t g = 0; g < ndevices; g++) {
+        trm_batch *b = nullptr;
+        int rc = trm_batch_create(params, devices[g], &b);
+        if (rc) {
+            trm_multi_destroy(m);
+            return rc;
+        }
+        m->b.push_back(b);
+    }
+    *out = m;
+    return TRM_OK;
+}
+
+void trm_multi_destroy(trm_multi *m)
+{
+    if (!m) return;
+    for (trm_batch *b : m->b) trm_batch_destroy(b);
+    delete m;
+}
+
+int trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                              const uint32_t *nframes, float *out, const uint64_t *out_offset,
+                              uint32_t *number_samples, float *max_sample)
+{
+    if (!m) return fail(TRM_EINVAL, "null handle");
+    if (nvoices == 0) return TRM_OK;
+    if (!frames || !frame_offset || !nframes || !out || !out_offset || !number_samples || !max_sample)
+        return fail(TRM_EINVAL, "null pointer");
+    const size_t G = m->b.size();
+    std::vector<size_t> bounds(G + 1);
+    trm_shard_voices(nframes, nvoices, G, bounds.data());
+    struct Shard {
+        size_t lo, hi;
+        uint64_t fLo, oLo, oHi;
+        std::vector<uint64_t> foff, ooff;
+        int rc = TRM_OK;
+        std::string err;
+    };
+    std::vector<Shard> sh(G);
+    for (size_t g = 0; g < G; g++) {
+        Shard &s = sh[g];
+        s.lo = bounds[g]; s.hi = bounds[g + 1];
+        s.fLo = s.oLo = ~0ull; s.oHi = 0;
+        for (size_t v = s.lo; v < s.hi; v++) {
+            if (nframes[v] && frame_offset[v] < s.fLo) s.fLo = frame_offset[v];
+            const uint64_t n = trm_batch_samples_for_frames(m->b[g], nframes[v]);
+            if (n && out_offset[v] < s.oLo) s.oLo = out_offset[v];
+            if (n && out_offset[v] + n > s.oHi) s.oHi = out_offset[v] + n;
+        }
+        if (s.fLo == ~0ull) s.fLo = 0;
+        if (s.oLo == ~0ull) s.oLo = s.oHi = 0;
+        for (size_t v = s.lo; v < s.hi; v++) {
+            s.foff.push_back(nframes[v] ? frame_offset[v] - s.fLo : 0);
+            s.ooff.push_back(trm_batch_samples_for_frames(m->b[g], nframes[v]) ? out_offset[v] - s.oLo : 0);
+        }
+    }
+    // a device copies back the whole span [oLo, oHi) of its shard: spans of different shards must be disjoint
+    for (size_t g = 0; g < G; g++)
+        for (size_t h = g + 1; h < G; h++)
+            if (sh[g].oHi > sh[g].oLo && sh[h].oHi > sh[h].oLo && sh[g].oLo < sh[h].oHi && sh[h].oLo < sh[g].oHi)
+                return fail(TRM_EINVAL, "output ranges of shards %zu and %zu interleave", g, h);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; g++) {
+        if (sh[g].hi == sh[g].lo) continue;
+        th.emplace_back([&, g]() {
+            Shard &s = sh[g];
+            s.rc = trm_batch_synthesize_host(m->b[g], s.hi - s.lo, frames + s.fLo * 16, s.foff.data(), nframes + s.lo,
+                                             out + s.oLo, s.ooff.data(), number_samples + s.lo, max_sample + s.lo);
+            if (s.rc) s.err = trm_last_error();      // (the detail text is thread-local: carry it to the caller's thread)
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+        if (sh[g].rc) return fail(sh[g].rc, "shard %zu (device %d): %s", g, m->b[g]->device, sh[g].err.c_str());
     return TRM_OK;
 }
 

@@ -147,7 +147,7 @@ int  trm_tube_generate_wav_data(trm_tube *tube, uint8_t *buf, size_t cap, size_t
 /* ------------------------------------------------------------------------------------
  * Batch entry (no reference equivalent: the reference builds one tube per utterance,
  * TRMSynthesizer.m:118-136; GnuTTSServer calls it once per utterance).  One call runs
- * V independent tubes that share one trm_input_params, one tube per lane.
+ * V independent tubes that share one trm_input_params.
  * ------------------------------------------------------------------------------------ */
 typedef struct trm_batch trm_batch;
 
@@ -180,6 +180,26 @@ int  trm_batch_synthesize_device(trm_batch *batch, size_t nvoices,
                                  float *d_out, const uint64_t *d_out_offset,
                                  uint32_t *d_number_samples, float *d_max_sample,
                                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Several GPUs from one process (voices are independent units -- contiguous voice ranges per device,
+ * private buffers, one host thread and one stream per device, no collective).  bench.py uses one PROCESS per GPU
+ * instead; the shard boundaries are the same function.
+ * --------------------------------------------------------------------------------------------- */
+/* bounds[0..nshards]: shard g = voices [bounds[g], bounds[g+1]), contiguous, covering all voices, balanced by frame
+ * count (a voice's cost is proportional to its frames).  Host-only. */
+int  trm_shard_voices(const uint32_t *nframes, size_t nvoices, size_t nshards, size_t *bounds);
+
+typedef struct trm_multi trm_multi;
+/* One trm_batch per entry of `devices` (a device may be listed more than once: its shards then share it). */
+int  trm_multi_create(const trm_input_params *params, const int *devices, size_t ndevices, trm_multi **out);
+void trm_multi_destroy(trm_multi *m);
+/* trm_batch_synthesize_host over all devices: same arguments and results.  Each device receives only its shard's
+ * frames and returns only its shard's PCM, so the output ranges of different shards must not interleave (voices laid
+ * out in index order, as TRMBatch does, satisfy this); TRM_EINVAL otherwise. */
+int  trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                               const uint32_t *nframes, float *out, const uint64_t *out_offset,
+                               uint32_t *number_samples, float *max_sample);
 
 /* Output normalisation on device, TRMTubeModel.m:370-389,420-484: int16 mono/stereo
  * from fp32 PCM with per-voice scale = 32767/max * amplitude(volume). */

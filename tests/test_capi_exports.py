@@ -100,3 +100,19 @@ def test_event_frame_count_needs_no_gpu():
     n = C.c_size_t()
     assert g.lib().trm_events_count_frames(times.ctypes.data, 3, C.byref(s), C.byref(n)) == 0
     assert n.value == 25                                           # t = 0, 4, ..., 96
+
+
+def test_shard_voices():
+    """trm_shard_voices: contiguous, covering, balanced by frame count; host-only."""
+    import gnuspeech_amd as g
+    assert g.shard_voices([10] * 8, 2) == [0, 4, 8]
+    assert g.shard_voices([100, 1, 1, 1, 1, 1, 1, 1], 2) == [0, 1, 8]           # one long utterance fills a shard
+    assert g.shard_voices([], 3) == [0, 0, 0, 0]
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = rng.integers(150, 1500, size=int(rng.integers(1, 400))).astype(np.uint32)
+        G = int(rng.integers(1, 9))
+        b = g.shard_voices(n, G)
+        assert b[0] == 0 and b[-1] == len(n) and all(x <= y for x, y in zip(b, b[1:]))
+        cost = [int(n[lo:hi].sum()) for lo, hi in zip(b, b[1:])]
+        assert max(cost) <= n.sum() / G + n.max()                              # within one voice of the even share

@@ -332,6 +332,47 @@ def test_host_entry_input_forms_and_kept_buffer(g, form):
     assert pcm4 == [] and len(ns4) == 0
 
 
+def test_several_devices_from_one_process(g, form):
+    """trm_multi_synthesize_host: shards on different batch objects (here: the one GPU listed three
+    times, one host thread and stream each) return what one batch returns, voice for voice; interleaved output
+    ranges are refused."""
+    pd = cases.monet_default_params(44100.0)
+    voices = cases.config4_frames(37, lo=3, hi=90) + [np.zeros((0, 16)), cases.load_gnuspeech_rows()[5:6].copy()]
+    ip = g.TRMInputParameters.from_dict(pd)
+    pcm, ns, mx = g.TRMBatch(ip).synthesize(voices)
+    m = g.TRMMultiBatch(ip, [0, 0, 0])
+    pcm2, ns2, mx2 = m.synthesize(voices)
+    assert np.array_equal(ns, ns2) and np.array_equal(mx, mx2)
+    for a, b in zip(pcm, pcm2):
+        assert np.array_equal(a, b)
+    pcm3, ns3, _ = g.TRMMultiBatch(ip, [0]).synthesize(voices[:1])              # fewer voices than shards, one shard
+    assert np.array_equal(pcm3[0], pcm[0])
+    pcm4, _, _ = m.synthesize(voices[:2])
+    assert np.array_equal(pcm4[1], pcm[1])
+    # voices laid out in REVERSE order in the output buffer: the shards' spans still do not interleave -> accepted;
+    # alternating voices between two halves of the buffer: refused
+    import ctypes as C
+    from gnuspeech_amd._capi import lib
+    nfr = np.array([len(v) for v in voices[:8]], dtype=np.uint32)
+    foff = np.concatenate([[0], np.cumsum(nfr[:-1])]).astype(np.uint64)
+    frames = np.concatenate([np.asarray(v, np.float32).reshape(-1, 16) for v in voices[:8]])
+    nout = np.array([m.samples_for_frames(n) for n in nfr], dtype=np.uint64)
+    total = int(nout.sum())
+    out = np.zeros(total, np.float32)
+    nsb, mxb = np.zeros(8, np.uint32), np.zeros(8, np.float32)
+    rev = (total - np.cumsum(nout)).astype(np.uint64)
+    args = lambda oo: (m._h, 8, frames.ctypes.data, foff.ctypes.data, nfr.ctypes.data, out.ctypes.data, oo.ctypes.data, nsb.ctypes.data, mxb.ctypes.data)
+    assert lib().trm_multi_synthesize_host(*args(rev)) == 0
+    for v in range(8):
+        assert np.array_equal(out[int(rev[v]):int(rev[v]) + int(nsb[v])], pcm[v])
+    half = total // 2 + 64
+    inter = np.array([(v // 2) * int(nout.max()) + (v % 2) * half for v in range(8)], dtype=np.uint64)
+    big = np.zeros(2 * half + 8 * int(nout.max()), np.float32)
+    a2 = (m._h, 8, frames.ctypes.data, foff.ctypes.data, nfr.ctypes.data, big.ctypes.data, inter.ctypes.data, nsb.ctypes.data, mxb.ctypes.data)
+    assert lib().trm_multi_synthesize_host(*a2) != 0
+    assert b"interleave" in lib().trm_last_error()
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
