@@ -299,6 +299,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     a.src_rows = b->dRows;
     a.sine = b->dSine;
     a.nvoices = (uint32_t)nvoices;
+    a.max_nframes = max_nframes;
     a.stamps = nullptr;
     a.stream_state = nullptr;
     a.stream_flags = a.stream_n_base = a.stream_k_base = a.stream_k_end = 0;
@@ -356,6 +357,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         d.max_sample = d_max_sample;
         d.fine = b->dFine;
         d.nvoices = (uint32_t)nvoices;
+        d.max_nframes = max_nframes;
         HIP_TRY(trm::launch_downsample(b->c, d, stream));
     }
     if (b->timing) {
@@ -488,6 +490,7 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         a.tube_out = nullptr;
         a.tube_offset = nullptr;
         a.nvoices = (uint32_t)V;
+        a.max_nframes = 0xFFFFFFFFu;          // (nframes is this function's own vector)
         a.stamps = nullptr;
             a.stream_state = s->dState.p;
         a.stream_flags = (s->first ? 1u : 0u) | (flush ? 2u : 0u);

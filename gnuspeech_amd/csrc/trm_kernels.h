@@ -32,6 +32,8 @@ struct TubeArgs {
     float *tube_out;
     const uint64_t *tube_offset;
     uint32_t nvoices;
+    uint32_t max_nframes;         // the host sized the noise table (and the tube rows) for this many frames per voice:
+                                  // a longer nframes[v] is cut to it (a caller's mistake must not run past them)
     unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product
     // Streaming (trm_tube_kernel_q only): a chunk of a longer utterance.  Null for one-shot synthesis.
     //   stream_state   kStreamFloats floats per voice, carried from one chunk to the next
@@ -73,6 +75,7 @@ struct DownArgs {
     float *max_sample;
     const float *fine;            // fine[q] = h[q>>8] + deltaH[q>>8]*(q&255)/256, q < 3328*256
     uint32_t nvoices;
+    uint32_t max_nframes;         // as in TubeArgs
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);

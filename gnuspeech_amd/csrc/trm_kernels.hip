@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
 
-    const uint32_t nfr = A.nframes[v];
+    const uint32_t nfr = min(A.nframes[v], A.max_nframes);
     const uint32_t nfrMax = wave_max_u32(nfr);          // same 64 voices in every wave of the group
     const uint32_t CP = (uint32_t)C.controlPeriod;
     const uint32_t inc = C.timeRegisterIncrement;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
 __global__ __launch_bounds__(256) void trm_downsample_kernel(const Const C, const DownArgs D)
 {
     const uint32_t v = blockIdx.x;
-    const uint32_t nfr = D.nframes[v];
+    const uint32_t nfr = min(D.nframes[v], D.max_nframes);
     const uint32_t pad = (uint32_t)C.padSize;
     const uint32_t ntube = nfr > 0 ? (nfr - 1) * (uint32_t)C.controlPeriod : 0;
     const uint32_t inc = C.timeRegisterIncrement;

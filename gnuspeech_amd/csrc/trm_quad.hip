@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
 
-    const uint32_t nfr = A.nframes[v];
+    const uint32_t nfr = min(A.nframes[v], A.max_nframes);
     const uint32_t nfrMax = wave_max_u32(nfr);
     const uint32_t CP = (uint32_t)C.controlPeriod;
     const uint32_t inc = C.timeRegisterIncrement;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         }
         const uint32_t ov = blockIdx.x * kQV + (uint32_t)lane;
         if (lane < kQV && ov < A.nvoices && C.upsample) {
-            const uint32_t nf = A.nframes[ov];
+            const uint32_t nf = min(A.nframes[ov], A.max_nframes);
             uint32_t nov = 0;
             if (streaming) nov = A.stream_k_end - kBase;
             else if (nf > 0) nov = (uint32_t)((((uint64_t)(nf - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);

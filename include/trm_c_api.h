@@ -173,7 +173,8 @@ int  trm_batch_synthesize_host(trm_batch *batch, size_t nvoices,
                                uint32_t *number_samples, float *max_sample);
 
 /* Device-buffer form (all pointers are HIP device pointers on the batch's device;
- * stream is a hipStream_t or NULL).  Asynchronous on `stream`. */
+ * stream is a hipStream_t or NULL).  Asynchronous on `stream`.  max_nframes = the largest d_nframes[v]: the
+ * voice-independent tables are sized from it, and a voice that claims more frames is cut to it. */
 int  trm_batch_synthesize_device(trm_batch *batch, size_t nvoices,
                                  const float *d_frames, const uint64_t *d_frame_offset,
                                  const uint32_t *d_nframes, uint32_t max_nframes,

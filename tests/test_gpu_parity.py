@@ -373,6 +373,27 @@ def test_several_devices_from_one_process(g, form):
     assert b"interleave" in lib().trm_last_error()
 
 
+def test_device_entry_cuts_voices_to_max_nframes(g, form):
+    """trm_batch_synthesize_device sizes its tables from max_nframes; a voice claiming more frames is cut to it
+    (same samples as the voice's first max_nframes frames), never run past them."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    rows = cases.load_gnuspeech_rows()
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    st = b.prepare_device([rows[:120].copy(), rows[10:50].copy()])
+    assert st["max_nframes"] == 120
+    st["max_nframes"] = 60
+    b.synthesize_device(st)
+    torch.cuda.synchronize()
+    pcm, ns, mx = b.synthesize([rows[:60].copy(), rows[10:50].copy()])
+    got = st["number_samples"].cpu().numpy()
+    assert [int(x) for x in got] == [int(x) for x in ns]
+    out = st["out"].cpu().numpy()
+    for v in range(2):
+        o0 = int(st["out_offset_host"][v])
+        assert np.array_equal(out[o0:o0 + int(ns[v])], pcm[v])
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
