@@ -394,6 +394,37 @@ def test_device_entry_cuts_voices_to_max_nframes(g, form):
         assert np.array_equal(out[o0:o0 + int(ns[v])], pcm[v])
 
 
+def test_garbage_control_values_terminate(g, form):
+    """NaN, infinities and absurd magnitudes in the control frames: no index is derived from data, so the launch ends,
+    the sample counts are those of the frame counts, and the sane voices beside them are untouched."""
+    pd = cases.monet_default_params(44100.0)
+    rows = cases.load_gnuspeech_rows()
+    rng = np.random.default_rng(99)
+    bad = []
+    for kind in range(6):
+        fr = rows[20:60].copy()
+        if kind == 0:
+            fr[5:, :] = np.nan
+        elif kind == 1:
+            fr[7, rng.integers(0, 16, 5)] = np.inf
+        elif kind == 2:
+            fr[:, :] = rng.standard_normal(fr.shape) * 1e30
+        elif kind == 3:
+            fr[:, 7:15] = 0.0                                  # every radius 0: 0/0 in the scattering coefficients
+        elif kind == 4:
+            fr[:, 0] = 1e9                                     # pitch: f0 overflows
+            fr[:, 4] = -1e9                                    # frication position far outside the tube
+        else:
+            fr[:, :] = -np.inf
+        bad.append(fr)
+    good = [rows[100:140].copy(), rows[0:40].copy()]
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    ref, nsr, _ = b.synthesize(good)
+    pcm, ns, mx = b.synthesize(bad[:3] + [good[0]] + bad[3:] + [good[1]])
+    assert all(int(n) == int(nsr[0]) for n in ns)
+    assert np.array_equal(pcm[3], ref[0]) and np.array_equal(pcm[7], ref[1])
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
