@@ -59,7 +59,7 @@ EXPORTS = [
     "trm_tube_save_output_to_file", "trm_tube_generate_wav_data", "trm_write_sound_file",
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
-    "trm_batch_synthesize_host", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
+    "trm_batch_synthesize_host", "trm_batch_synthesize_host_int16", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
     "trm_shard_voices", "trm_multi_create", "trm_multi_destroy", "trm_multi_synthesize_host",
     "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
     "trm_stream_push", "trm_stream_finish",
@@ -123,6 +123,7 @@ def lib():
     L.trm_samples_for_frames.argtypes = [C.POINTER(TrmInputParams), C.c_size_t]
     L.trm_samples_for_frames.restype = C.c_size_t
     L.trm_batch_synthesize_host.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
+    L.trm_batch_synthesize_host_int16.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.trm_shard_voices.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
     L.trm_multi_create.argtypes = [C.POINTER(TrmInputParams), vp, C.c_size_t, C.POINTER(vp)]
     L.trm_multi_destroy.argtypes = [vp]

@@ -42,7 +42,15 @@ class TRMBatch:
         the next call."""
         return self._synthesize_host(lib().trm_batch_synthesize_host, voices, reuse_output)
 
-    def _synthesize_host(self, entry, voices, reuse_output):
+    def synthesize_int16(self, voices, for_wav_data=False, reuse_output=False):
+        """As synthesize(), returning the containers' int16 PCM (TRMTubeModel.m:370-389 / :515-540): per voice an
+        int16 array [n] (mono) or [n, 2] (inputParameters.channels == 2); the scaling runs on the device and half the
+        bytes cross PCIe."""
+        ch = 2 if self.inputParameters.channels == 2 else 1
+        return self._synthesize_host(lib().trm_batch_synthesize_host_int16, voices, reuse_output, dtype=np.int16, channels=ch,
+                                     extra=(int(bool(for_wav_data)),))
+
+    def _synthesize_host(self, entry, voices, reuse_output, dtype=np.float32, channels=1, extra=()):
         V = len(voices)
         if isinstance(voices, np.ndarray) and voices.ndim == 3:
             nfr = np.full(V, voices.shape[1], dtype=np.uint32)
@@ -66,17 +74,21 @@ class TRMBatch:
         if V > 1:
             ooff[1:V] = np.cumsum(nout[:-1], dtype=np.uint64)
         total = max(1, int(nout.sum()))
+        total *= channels
         if reuse_output:
-            if getattr(self, "_host_out", None) is None or self._host_out.size < total:
-                self._host_out = np.ones(total + total // 8, dtype=np.float32)      # ones: every page touched
-            out = self._host_out[:total]
+            nbytes = total * np.dtype(dtype).itemsize
+            if getattr(self, "_host_out", None) is None or self._host_out.size < nbytes:
+                self._host_out = np.ones(nbytes + nbytes // 8, dtype=np.uint8)      # ones: every page touched
+            out = self._host_out[:nbytes].view(dtype)
         else:
-            out = np.zeros(total, dtype=np.float32)
+            out = np.zeros(total, dtype=dtype)
         ns = np.zeros(max(1, V), dtype=np.uint32)
         mx = np.zeros(max(1, V), dtype=np.float32)
         nfr_c = np.ascontiguousarray(nfr if V else np.zeros(1, np.uint32))
         check(entry(self._h, V, frames.ctypes.data, foff.ctypes.data, nfr_c.ctypes.data,
-                                              out.ctypes.data, ooff.ctypes.data, ns.ctypes.data, mx.ctypes.data))
+                                              out.ctypes.data, ooff.ctypes.data, ns.ctypes.data, mx.ctypes.data, *extra))
+        if channels == 2:
+            out = out.reshape(-1, 2)
         pcm = [out[int(ooff[v]):int(ooff[v]) + int(ns[v])] for v in range(V)]
         return pcm, ns[:V], mx[:V]
 

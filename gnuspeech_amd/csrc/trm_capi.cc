@@ -79,6 +79,7 @@ struct trm_batch {
     uint32_t noiseLen = 0;
     // host-form staging
     DevBuf<float> dFrames, dOut, dMax;
+    DevBuf<int16_t> dOut16;
     DevBuf<uint64_t> dFrameOff, dOutOff;
     DevBuf<uint32_t> dNFrames, dNSamples;
     // kernel timing (hipEvents on the launch stream)
@@ -588,13 +589,14 @@ int trm_batch_noise_table(trm_batch *b, float *host_out, size_t n)
     return TRM_OK;
 }
 
-int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames, const uint64_t *frame_offset,
-                              const uint32_t *nframes, float *out, const uint64_t *out_offset,
-                              uint32_t *number_samples, float *max_sample)
+// host-buffer entry: fp32 PCM (out) or the containers' int16 (out16, mono or interleaved stereo), not both
+static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                                const uint32_t *nframes, float *out, int16_t *out16, int for_wav_data,
+                                const uint64_t *out_offset, uint32_t *number_samples, float *max_sample)
 {
     if (!b) return fail(TRM_EINVAL, "null batch");
     if (nvoices == 0) return TRM_OK;
-    if (!frames || !frame_offset || !nframes || !out || !out_offset || !number_samples || !max_sample)
+    if (!frames || !frame_offset || !nframes || (!out && !out16) || !out_offset || !number_samples || !max_sample)
         return fail(TRM_EINVAL, "null pointer");
     HIP_TRY(hipSetDevice(b->device));
     uint64_t frameRows = 0, outEnd = 0;
@@ -607,11 +609,13 @@ int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames,
         if (nframes[v] > maxFrames) maxFrames = nframes[v];
     }
     if (frameRows == 0) frameRows = 1;
+    const size_t ch = b->params.channels == 2 ? 2 : 1;
     int rc;
     if ((rc = b->dFrames.reserve(frameRows * 16)) || (rc = b->dOut.reserve(outEnd + 1)) ||
         (rc = b->dFrameOff.reserve(nvoices)) || (rc = b->dOutOff.reserve(nvoices)) ||
         (rc = b->dNFrames.reserve(nvoices)) || (rc = b->dNSamples.reserve(nvoices)) || (rc = b->dMax.reserve(nvoices)))
         return rc;
+    if (out16 && (rc = b->dOut16.reserve(outEnd * ch + 1))) return rc;
     hipStream_t s = b->stream;
     HIP_TRY(hipMemcpyAsync(b->dFrames.p, frames, frameRows * 16 * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->dFrameOff.p, frame_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
@@ -620,11 +624,35 @@ int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames,
     rc = trm_batch_synthesize_device(b, nvoices, b->dFrames.p, b->dFrameOff.p, b->dNFrames.p, maxFrames, b->dOut.p,
                                      b->dOutOff.p, b->dNSamples.p, b->dMax.p, s);
     if (rc) return rc;
-    if (outEnd) HIP_TRY(hipMemcpyAsync(out, b->dOut.p, outEnd * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (out16) {
+        rc = trm_batch_scale_to_int16_device(b, nvoices, b->dOut.p, b->dOutOff.p, b->dNSamples.p, b->dMax.p, b->dOut16.p,
+                                             for_wav_data, s);
+        if (rc) return rc;
+        if (outEnd) HIP_TRY(hipMemcpyAsync(out16, b->dOut16.p, outEnd * ch * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    } else if (outEnd) {
+        HIP_TRY(hipMemcpyAsync(out, b->dOut.p, outEnd * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipMemcpyAsync(number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return TRM_OK;
+}
+
+int trm_batch_synthesize_host(trm_batch *b, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                              const uint32_t *nframes, float *out, const uint64_t *out_offset,
+                              uint32_t *number_samples, float *max_sample)
+{
+    if (!out) return fail(TRM_EINVAL, "null pointer");
+    return synthesize_host_impl(b, nvoices, frames, frame_offset, nframes, out, nullptr, 0, out_offset, number_samples, max_sample);
+}
+
+int trm_batch_synthesize_host_int16(trm_batch *b, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                                    const uint32_t *nframes, int16_t *out16, const uint64_t *out_offset,
+                                    uint32_t *number_samples, float *max_sample, int for_wav_data)
+{
+    if (!out16) return fail(TRM_EINVAL, "null pointer");
+    return synthesize_host_impl(b, nvoices, frames, frame_offset, nframes, nullptr, out16, for_wav_data, out_offset, number_samples,
+                                max_sample);
 }
 
 // ------------------------------------------------------------------ several devices from one process

@@ -172,6 +172,16 @@ int  trm_batch_synthesize_host(trm_batch *batch, size_t nvoices,
                                float *out, const uint64_t *out_offset,
                                uint32_t *number_samples, float *max_sample);
 
+/* The same, returning what -saveOutputToFile: / -generateWAVData put into their containers (TRMTubeModel.m:370-389,
+ * 515-540): int16 PCM scaled per voice by 32767/max * amplitude(volume), mono or -- params->channels == 2 --
+ * interleaved stereo with the balance applied (for_wav_data != 0: -generateWAVData's variant without the x2).  Voice v's
+ * first value is out16[out_offset[v] * channels]; half the bytes of the fp32 form cross PCIe. */
+int  trm_batch_synthesize_host_int16(trm_batch *batch, size_t nvoices,
+                                     const float *frames, const uint64_t *frame_offset,
+                                     const uint32_t *nframes,
+                                     int16_t *out16, const uint64_t *out_offset,
+                                     uint32_t *number_samples, float *max_sample, int for_wav_data);
+
 /* Device-buffer form (all pointers are HIP device pointers on the batch's device;
  * stream is a hipStream_t or NULL).  Asynchronous on `stream`.  max_nframes = the largest d_nframes[v]: the
  * voice-independent tables are sized from it, and a voice that claims more frames is cut to it. */

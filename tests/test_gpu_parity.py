@@ -425,6 +425,29 @@ def test_garbage_control_values_terminate(g, form):
     assert np.array_equal(pcm[3], ref[0]) and np.array_equal(pcm[7], ref[1])
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_host_entry_int16(g, form, channels):
+    """trm_batch_synthesize_host_int16: the containers' int16 PCM straight from the device == the oracle's scaling
+    (TRMTubeModel.m:370-389 file form, :515-540 WAV-data form) of the same launch's fp32 PCM, ragged batch, mono and
+    stereo with balance."""
+    pd = cases.monet_default_params(44100.0)
+    pd["channels"] = channels
+    pd["balance"] = 0.3
+    pd["volume"] = 57.0
+    voices = cases.config4_frames(9, lo=3, hi=70) + [np.zeros((0, 16)), cases.load_gnuspeech_rows()[5:6].copy()]
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    pcm, ns, mx = b.synthesize(voices)
+    op = O.InputParams.from_dict(pd)
+    for wav in (False, True):
+        p16, ns16, mx16 = b.synthesize_int16(voices, for_wav_data=wav, reuse_output=wav)
+        assert np.array_equal(ns, ns16) and np.array_equal(mx, mx16)
+        for v in range(len(voices)):
+            if int(ns[v]) == 0 or float(mx[v]) == 0.0:
+                continue
+            ref = np.asarray(O.scale_int16(op, pcm[v].astype(np.float64), float(mx[v]), for_wav_data=wav)).reshape(p16[v].shape)
+            assert np.array_equal(p16[v], ref), (wav, v)
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the

@@ -20,3 +20,10 @@ for name, arg, reuse in (("list of voices, fresh output buffer", voices, False),
     dt = time.perf_counter() - t0
     print("host-buffer entry, %d voices x 1 s, %s: %.1f ms -> %.3e samples/s (frame packing + H2D + kernel + D2H fp32 PCM)" % (
         V, name, dt * 1e3, int(ns.sum()) / dt))
+arr = np.ascontiguousarray(fr, dtype=np.float32)
+b.synthesize_int16(arr, reuse_output=True)
+t0 = time.perf_counter()
+pcm, ns, mx = b.synthesize_int16(arr, reuse_output=True)
+dt = time.perf_counter() - t0
+print("host-buffer entry, %d voices x 1 s, [V,N,16] array, kept output buffer, int16 PCM out (scaled on the device): %.1f ms -> %.3e samples/s" % (
+    V, dt * 1e3, int(ns.sum()) / dt))
