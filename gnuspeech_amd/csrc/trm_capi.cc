@@ -72,6 +72,8 @@ struct trm_batch {
     trm::Const *dConst = nullptr;
     float *dRowsAlloc = nullptr, *dRows = nullptr, *dSine = nullptr;
     float *dFine = nullptr;              // down-sampling batches only
+    float *dDownRows = nullptr;          // down-sampling batches only: per-phase coefficient rows
+    uint32_t downL = 0, downR = 0, downPitch = 0;
     DevBuf<float> dTube;                 // down-sampling: tube-rate samples between the two kernels
     DevBuf<uint64_t> dTubeOff;
     DevBuf<float> dNoise;
@@ -198,6 +200,13 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
         trm::build_src_fine(fine);
         B_TRY(hipMalloc((void **)&b->dFine, fine.size() * sizeof(float)));
         B_TRY(hipMemcpy(b->dFine, fine.data(), fine.size() * sizeof(float), hipMemcpyHostToDevice));
+        // rows of the tiled down-sampling kernel (launch_downsample falls back to walking `fine` when a row is too wide)
+        if (c.phaseIncrement > 0 && trm::kSrcFineLen / c.phaseIncrement <= 160) {
+            std::vector<float> drows;
+            trm::build_down_rows(fine, c.sampleRateRatioD, c.phaseIncrement, b->downL, b->downR, b->downPitch, drows);
+            B_TRY(hipMalloc((void **)&b->dDownRows, drows.size() * sizeof(float)));
+            B_TRY(hipMemcpy(b->dDownRows, drows.data(), drows.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
 #undef B_TRY
     *out = b;
@@ -213,6 +222,7 @@ void trm_batch_destroy(trm_batch *b)
     if (b->dRowsAlloc) (void)hipFree(b->dRowsAlloc);
     if (b->dSine) (void)hipFree(b->dSine);
     if (b->dFine) (void)hipFree(b->dFine);
+    if (b->dDownRows) (void)hipFree(b->dDownRows);
     if (b->dNoiseState) (void)hipFree(b->dNoiseState);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -309,7 +319,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     if (!b->c.upsample) {
         // tube rate above the output rate: tube-rate samples go through HBM to the down-sampling kernel;
         // voice v gets a fixed-pitch row of (max_nframes-1)*controlPeriod + 2*pad floats
-        const uint64_t pitch = ntubeMax + 2ull * (uint64_t)b->d.padSize;
+        const uint64_t pitch = (ntubeMax + 2ull * (uint64_t)b->d.padSize + 3ull) & ~3ull;      // rows 16-byte aligned
         if ((rc = b->dTube.reserve(pitch * nvoices + 1)) || (rc = b->dTubeOff.reserve(nvoices))) return rc;
         std::vector<uint64_t> offs(nvoices);
         for (size_t i = 0; i < nvoices; i++) offs[i] = pitch * i;
@@ -359,6 +369,8 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         d.fine = b->dFine;
         d.nvoices = (uint32_t)nvoices;
         d.max_nframes = max_nframes;
+        d.rows = getenv("TRM_DOWNSAMPLE_GENERIC") ? nullptr : b->dDownRows;     // (tests: the generic kernel must agree bit for bit)
+        d.lmax = b->downL; d.rmax = b->downR; d.pitch = b->downPitch;
         HIP_TRY(trm::launch_downsample(b->c, d, stream));
     }
     if (b->timing) {

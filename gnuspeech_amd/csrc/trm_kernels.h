@@ -76,6 +76,9 @@ struct DownArgs {
     const float *fine;            // fine[q] = h[q>>8] + deltaH[q>>8]*(q&255)/256, q < 3328*256
     uint32_t nvoices;
     uint32_t max_nframes;         // as in TubeArgs
+    // per-phase coefficient rows (trm_setup.h: build_down_rows); null / too wide for LDS: the generic kernel walks `fine`
+    const float *rows;
+    uint32_t lmax, rmax, pitch;
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);

@@ -466,6 +466,83 @@ __global__ __launch_bounds__(256) void trm_downsample_kernel(const Const C, cons
     }
 }
 
+// The same branch for the ratios that occur in practice (16 kHz, 8 kHz output from a 19.75 kHz tube), tiled: a
+// workgroup = 32 consecutive outputs x 8 voices.  All voices share an output's phase, so its coefficient row (built once
+// per batch object, DownArgs::rows) and each voice's window of tube samples are staged in LDS and every thread runs the
+// reference's two wing loops over them -- same products in the same order as trm_downsample_kernel (taps past a wing's
+// end multiply by 0).  The per-voice maximum is an atomic max on the float's bits (non-negative), max_sample zeroed by
+// the launcher.
+constexpr int kDownCols = 32, kDownVoices = 32, kDownPerThread = 4;      // 256 threads: 32 outputs x 8 voice groups x 4 voices each
+__global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_downsample_rows_kernel(const Const C, const DownArgs D, uint32_t xlen)
+{
+    extern __shared__ float sDown[];
+    const uint32_t T = D.lmax + D.rmax, rp = T | 1u;          // odd LDS pitch: the 32 rows land in 32 banks
+    float *const sRow = sDown;                                // [32][rp]
+    float *const sXw = sDown + kDownCols * rp;                // [32 voices][xlen]
+    __shared__ uint32_t sNt[kDownVoices];
+    __shared__ uint64_t sOff[kDownVoices];
+    constexpr uint32_t kGroups = kDownVoices / kDownPerThread;
+    const uint32_t tid = threadIdx.x, o = tid & (kDownCols - 1), w = tid / kDownCols;      // w: voice group 0..7
+    const uint32_t pad = (uint32_t)C.padSize, inc = C.timeRegisterIncrement, CP = (uint32_t)C.controlPeriod;
+    const uint32_t k0 = blockIdx.x * kDownCols, v0 = blockIdx.y * kDownVoices;
+    if (tid < (uint32_t)kDownVoices) {
+        const uint32_t vv = v0 + tid;
+        const uint32_t nfr = vv < D.nvoices ? min(D.nframes[vv], D.max_nframes) : 0u;
+        sNt[tid] = nfr > 0 ? (nfr - 1) * CP : 0u;
+        sOff[tid] = vv < D.nvoices ? D.tube_offset[vv] : 0ull;
+    }
+    // the block's rows: output k0 + r has phase ((k0 + r) * inc) & 0xFFFF; 8 threads per row
+    for (uint32_t r = tid >> 3; r < (uint32_t)kDownCols; r += blockDim.x >> 3) {
+        const float *src = D.rows + (size_t)src_phase(k0 + r, inc) * D.pitch;
+        for (uint32_t i = tid & 7u; i < T; i += 8) sRow[r * rp + i] = src[i];
+    }
+    __syncthreads();
+    // every voice's window: tube samples nLo .. nLo + xlen - 1 (zeros outside the voice's own samples); 8 threads per voice
+    const int64_t nLo = (int64_t)src_position(k0, inc) - (int64_t)pad - (int64_t)(D.lmax - 1);
+    for (uint32_t ww = tid >> 3; ww < (uint32_t)kDownVoices; ww += blockDim.x >> 3) {
+        const float *src = D.tube + sOff[ww];
+        const int64_t nt = (int64_t)sNt[ww];
+        for (uint32_t i = tid & 7u; i < xlen; i += 8) {
+            const int64_t n = nLo + (int64_t)i;
+            sXw[ww * xlen + i] = (n >= 0 && n < nt) ? src[n] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const uint32_t k = k0 + o;
+    const float *row = &sRow[o * rp];
+    const uint32_t centre = (uint32_t)((int64_t)src_position(k, inc) - (int64_t)pad - nLo);       // tube sample e - pad in the window
+    // this thread's four voices: w, w + 8, w + 16, w + 24 of the tile; one coefficient read feeds four products
+    float acc[kDownPerThread];
+    const float *xw[kDownPerThread];
+    for (int q = 0; q < kDownPerThread; q++) {
+        acc[q] = 0.0f;
+        xw[q] = &sXw[(w + q * kGroups) * xlen + centre];
+    }
+    for (uint32_t j = 0; j < D.lmax; j++) {
+        const float c = row[j];
+        for (int q = 0; q < kDownPerThread; q++) acc[q] += xw[q][-(int)j] * c;
+    }
+    for (uint32_t j = 0; j < D.rmax; j++) {
+        const float c = row[D.lmax + j];
+        for (int q = 0; q < kDownPerThread; q++) acc[q] += xw[q][1 + j] * c;
+    }
+    for (int q = 0; q < kDownPerThread; q++) {
+        const uint32_t wl = w + q * kGroups, v = v0 + wl;
+        const bool voiced = v < D.nvoices && min(D.nframes[v < D.nvoices ? v : 0], D.max_nframes) > 0;
+        const uint32_t nout = voiced ? (uint32_t)((((uint64_t)sNt[wl] + 2ull * pad) * 65536ull + inc - 1) / inc) : 0u;
+        float m = 0.0f;
+        if (k < nout) {
+            (D.out + D.out_offset[v])[k] = acc[q];
+            m = fabsf(acc[q]);
+        }
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));     // the 32 lanes of this voice
+        if (o == 0 && v < D.nvoices) {
+            if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(&D.max_sample[v]), __float_as_uint(m));
+            if (blockIdx.x == 0) D.number_samples[v] = nout;
+        }
+    }
+}
+
 // Output normalisation (TRMTubeModel.m:370-389 file path, :515-533 WAV-data path).  One
 // workgroup per voice; mono -> int16[n], stereo -> interleaved int16[2n].
 __global__ __launch_bounds__(256) void trm_int16_kernel(const ScaleArgs S)
@@ -518,6 +595,20 @@ int tube_kernel_blocks_per_cu()
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
+    // the tiled kernel where its rows and windows fit LDS comfortably (any speech-rate ratio does), else the generic walk
+    const uint32_t T = a.lmax + a.rmax;
+    const uint32_t xlen = (uint32_t)(((uint64_t)(kDownCols - 1) * c.timeRegisterIncrement) >> 16) + 2u + T;
+    const size_t lds = ((size_t)kDownCols * (T | 1u) + (size_t)kDownVoices * xlen) * sizeof(float);
+    if (a.rows && T > 0 && lds <= 48 * 1024) {
+        const uint32_t ntubeMax = a.max_nframes > 0 ? (a.max_nframes - 1) * (uint32_t)c.controlPeriod : 0;
+        const uint64_t noutMax = (((uint64_t)ntubeMax + 2ull * (uint32_t)c.padSize) * 65536ull + c.timeRegisterIncrement - 1) / c.timeRegisterIncrement;
+        hipError_t e = hipMemsetAsync(a.max_sample, 0, a.nvoices * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+        const dim3 grid((unsigned)((noutMax + kDownCols - 1) / kDownCols > 0 ? (noutMax + kDownCols - 1) / kDownCols : 1),
+                        (a.nvoices + kDownVoices - 1) / kDownVoices);
+        hipLaunchKernelGGL(trm_downsample_rows_kernel, grid, dim3(kDownCols * kDownVoices / kDownPerThread), lds, stream, c, a, xlen);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(trm_downsample_kernel, dim3(a.nvoices), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }

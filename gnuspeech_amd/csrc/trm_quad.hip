@@ -517,9 +517,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     ring[slot4] = yy;
                     if (slot4 < (uint32_t)(kYMirror / 4)) ring[slot4 + kYRing / 4] = yy;
                     if (tubeOut && laneValid) {
+                        // (rows of tube_out are 16-byte aligned: the host pads their pitch to 4 floats)
                         const uint32_t lim = ntubeLane + (sLast ? 2u * (uint32_t)C.padSize : 0u);
-                        for (int s = 0; s < kQB; s++)
-                            if (n0 + s < lim) tubeOut[n0 + s] = y[s];
+                        if (n0 + kQB <= lim) *reinterpret_cast<float4 *>(tubeOut + n0) = yy;
+                        else
+                            for (int s = 0; s < kQB; s++)
+                                if (n0 + s < lim) tubeOut[n0 + s] = y[s];
                     }
                 }
               }

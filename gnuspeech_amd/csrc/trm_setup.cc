@@ -162,6 +162,23 @@ void build_src_fine(std::vector<float> &fine)
         fine[q] = (float)(h[q >> 8] + dh[q >> 8] * ((double)(q & 255) / 256.0));
 }
 
+void build_down_rows(const std::vector<float> &fine, double ratio, uint32_t phaseIncrement, uint32_t &lmax,
+                     uint32_t &rmax, uint32_t &pitch, std::vector<float> &rows)
+{
+    const uint32_t span = (uint32_t)kSrcLen * 256u;               // the wings end where (ph >> 8) reaches kSrcLen
+    // both wings start at rint(f' * ratio) >= 0 for some 16-bit f': at most this many taps
+    lmax = rmax = (span + phaseIncrement - 1) / phaseIncrement;
+    pitch = (lmax + rmax + 3u) & ~3u;
+    rows.assign((size_t)65536 * pitch, 0.0f);
+    for (uint32_t f = 0; f < 65536u; f++) {
+        float *row = &rows[(size_t)f * pitch];
+        uint32_t ph = (uint32_t)rint((double)f * ratio);                              // :243
+        for (uint32_t j = 0; j < lmax && (ph >> 8) < (uint32_t)kSrcLen; j++, ph += phaseIncrement) row[j] = fine[ph];
+        ph = (uint32_t)rint((double)((~f) & 0xFFFFu) * ratio);                        // :257
+        for (uint32_t j = 0; j < rmax && (ph >> 8) < (uint32_t)kSrcLen; j++, ph += phaseIncrement) row[lmax + j] = fine[ph];
+    }
+}
+
 void build_sine_table(std::vector<float> &tab)
 {
     tab.resize(kTableLen);

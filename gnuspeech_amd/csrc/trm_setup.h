@@ -29,7 +29,13 @@ void build_src_rows(std::vector<float> &rows);
 
 // Fine table for the down-sampling branch: fine[q] = h[q>>8] + deltaH[q>>8]*(q&255)/256,
 // q < 3328*256 (TRMSampleRateConverter.m:246-270).
+constexpr uint32_t kSrcFineLen = 13u * 256u * 256u;    // entries of the fine table: FILTER_LENGTH x 256
 void build_src_fine(std::vector<float> &fine);
+// Down-sampling branch, per 16-bit phase f of the time register: the coefficients the reference's two wing loops
+// (TRMSampleRateConverter.m:243-270) walk through, laid out per output as [left tap 0 .. lmax-1 | right tap 0 .. rmax-1]
+// (taps past a wing's own end: 0), `pitch` floats per row.  Same values as trm_downsample_kernel's own walk.
+void build_down_rows(const std::vector<float> &fine, double ratio, uint32_t phaseIncrement, uint32_t &lmax,
+                     uint32_t &rmax, uint32_t &pitch, std::vector<float> &rows);
 
 // Exact number of converter outputs for a tube that received `ntube` samples, following the
 // ring-buffer bookkeeping literally (TRMRingBuffer.m:47-93, TRMSampleRateConverter.m:155-298),

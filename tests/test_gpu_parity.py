@@ -136,6 +136,24 @@ def test_downsampling_batch(g, form):
     _batch_vs_oracle(g, pd, voices)
 
 
+@pytest.mark.parametrize("rate", [16000.0, 8000.0, 11025.0])
+def test_downsampling_speech_rates(g, form, rate, monkeypatch):
+    """The Monet default tube (19 750 Hz) into 16 / 8 / 11.025 kHz output: the tiled down-sampling kernel (per-phase
+    coefficient rows in LDS) vs the oracle, and bit for bit vs the generic kernel that walks the fine table like the
+    reference's loops (TRMSampleRateConverter.m:234-297).  Ragged batch incl. 0-, 1-, 2-frame voices."""
+    pd = cases.monet_default_params(rate)
+    rows = cases.load_gnuspeech_rows()
+    voices = cases.config4_frames(11, lo=3, hi=70) + [np.zeros((0, 16)), rows[5:6].copy(), rows[100:102].copy(), rows[0:130].copy()]
+    worst = _batch_vs_oracle(g, pd, voices)
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    pcm, ns, mx = b.synthesize(voices)
+    monkeypatch.setenv("TRM_DOWNSAMPLE_GENERIC", "1")
+    pcm2, ns2, mx2 = b.synthesize(voices)
+    assert np.array_equal(ns, ns2) and np.array_equal(mx, mx2)
+    for a, c in zip(pcm, pcm2):
+        assert np.array_equal(a, c)
+
+
 def test_extreme_rate_ratios(g, form):
     """Converter ratios at both ends of the up-sampling range: a 30 cm tube (tube rate ~11.7 kHz, ratio 3.8 at
     44.1 kHz: the converter produces ~15 outputs per pipeline step) and a 15.8 cm tube at 22.05 kHz (ratio 1.008)."""
