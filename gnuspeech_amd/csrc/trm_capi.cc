@@ -371,6 +371,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         d.max_nframes = max_nframes;
         d.rows = getenv("TRM_DOWNSAMPLE_GENERIC") ? nullptr : b->dDownRows;     // (tests: the generic kernel must agree bit for bit)
         d.lmax = b->downL; d.rmax = b->downR; d.pitch = b->downPitch;
+        d.stream = 0; d.n_origin = d.n_hi = 0; d.k_base = d.k_end = 0;
         HIP_TRY(trm::launch_downsample(b->c, d, stream));
     }
     if (b->timing) {
@@ -385,6 +386,9 @@ struct trm_stream {
     trm_batch *b = nullptr;
     size_t nvoices = 0;
     DevBuf<float> dState, dFrames, dOut, dMax;
+    DevBuf<float> dTube, dHist;       // down-sampling streams: [history | chunk] tube-rate rows; the history between chunks
+    DevBuf<uint64_t> dTubeOff, dTubeOff0;
+    uint32_t hist = 0;                // tube samples of history a chunk's first output may reach back (multiple of 4)
     DevBuf<uint64_t> dFrameOff, dOutOff;
     DevBuf<uint32_t> dNFrames, dNSamples;
     std::vector<float> lastFrame;     // [nvoices][16]: the frame the next control period starts from
@@ -401,15 +405,24 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
     trm_batch *b = nullptr;
     int rc = trm_batch_create(params, device, &b);
     if (rc) return rc;
-    if (!b->c.upsample) {
+    if (!b->c.upsample && (!b->dDownRows || b->downR > (uint32_t)b->d.padSize || b->downL > (uint32_t)b->d.padSize + 1u)) {
+        // (a chunk emits the outputs whose read position lies inside it; their right wing must end there too)
         trm_batch_destroy(b);
-        return fail(TRM_ERANGE, "streaming carries up-sampling voices only (tube rate %d Hz above the output rate)", b->d.sampleRate);
+        return fail(TRM_ERANGE, "streaming: output rate too far below the tube rate (%d Hz) for the tiled down-sampling kernel", b->d.sampleRate);
     }
     trm_stream *s = new (std::nothrow) trm_stream();
     if (!s) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_stream"); }
     s->b = b;
     s->nvoices = nvoices;
     s->lastFrame.assign(nvoices * 16, 0.0f);
+    if (!b->c.upsample) {
+        s->hist = (2u * (uint32_t)b->d.padSize + 3u) & ~3u;
+        if ((rc = s->dHist.reserve(nvoices * s->hist)) || (rc = s->dTubeOff.reserve(nvoices)) || (rc = s->dTubeOff0.reserve(nvoices))) {
+            delete s;
+            trm_batch_destroy(b);
+            return rc;
+        }
+    }
     if ((rc = s->dState.reserve(nvoices * trm::kStreamFloats)) || (rc = s->dFrameOff.reserve(nvoices)) || (rc = s->dOutOff.reserve(nvoices)) ||
         (rc = s->dNFrames.reserve(nvoices)) || (rc = s->dNSamples.reserve(nvoices)) || (rc = s->dMax.reserve(nvoices))) {
         trm_stream_destroy(s);
@@ -471,6 +484,8 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = b->stream;
     int rc;
+    const bool down = !b->c.upsample;
+    const size_t rowPitch = ((size_t)s->hist + (size_t)N + 2u * (size_t)b->d.padSize + 3u) & ~(size_t)3;     // down-sampling streams
     if ((rc = s->dFrames.reserve(V * rows * 16)) || (rc = s->dOut.reserve(V * (size_t)count + 64))) return rc;
     s->hostFrames.resize(V * rows * 16);
     std::vector<uint64_t> foff(V), ooff(V);
@@ -502,6 +517,20 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         a.sine = b->dSine;
         a.tube_out = nullptr;
         a.tube_offset = nullptr;
+        if (down) {
+            // rows of [history | the chunk's tube samples (| the flush zeros)]; the tube stage writes behind the history
+            if ((rc = s->dTube.reserve(V * rowPitch + 4))) return rc;
+            std::vector<uint64_t> t0(V), t1(V);
+            for (size_t v = 0; v < V; v++) { t0[v] = v * rowPitch; t1[v] = v * rowPitch + s->hist; }
+            HIP_TRY(hipMemcpyAsync(s->dTubeOff0.p, t0.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->dTubeOff.p, t1.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));          // t0 / t1 are stack temporaries
+            if (s->first) HIP_TRY(hipMemsetAsync(s->dHist.p, 0, V * s->hist * sizeof(float), st));
+            HIP_TRY(hipMemcpy2DAsync(s->dTube.p, rowPitch * sizeof(float), s->dHist.p, s->hist * sizeof(float), s->hist * sizeof(float), V,
+                                     hipMemcpyDeviceToDevice, st));
+            a.tube_out = s->dTube.p;
+            a.tube_offset = s->dTubeOff.p;
+        }
         a.nvoices = (uint32_t)V;
         a.max_nframes = 0xFFFFFFFFu;          // (nframes is this function's own vector)
         a.stamps = nullptr;
@@ -512,6 +541,34 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         a.stream_k_end = (uint32_t)kEnd;
         HIP_TRY(trm::launch_tube_quad(b->c, a, st));
         s->first = false;
+        if (down) {
+            if (count > 0) {
+                trm::DownArgs d;
+                d.tube = s->dTube.p;
+                d.tube_offset = s->dTubeOff0.p;
+                d.nframes = s->dNFrames.p;
+                d.out = s->dOut.p;
+                d.out_offset = s->dOutOff.p;
+                d.number_samples = s->dNSamples.p;
+                d.max_sample = s->dMax.p;
+                d.fine = b->dFine;
+                d.nvoices = (uint32_t)V;
+                d.max_nframes = 0xFFFFFFFFu;
+                d.rows = b->dDownRows;
+                d.lmax = b->downL; d.rmax = b->downR; d.pitch = b->downPitch;
+                d.stream = 1;
+                d.n_origin = (long long)s->nBase - (long long)s->hist;
+                d.n_hi = (long long)(s->nBase + N + (flush ? 2ull * (uint64_t)b->d.padSize : 0ull));
+                d.k_base = (uint32_t)s->kBase;
+                d.k_end = (uint32_t)kEnd;
+                HIP_TRY(trm::launch_downsample(b->c, d, st));
+            } else {
+                HIP_TRY(hipMemsetAsync(s->dMax.p, 0, V * sizeof(float), st));
+            }
+            // the next chunk's history: the last `hist` tube samples so far (row positions N .. N + hist - 1)
+            HIP_TRY(hipMemcpy2DAsync(s->dHist.p, s->hist * sizeof(float), s->dTube.p + N, rowPitch * sizeof(float), s->hist * sizeof(float), V,
+                                     hipMemcpyDeviceToDevice, st));
+        }
     }
     if (count > 0) {
         s->hostOut.resize(V * (size_t)count);

@@ -79,6 +79,13 @@ struct DownArgs {
     // per-phase coefficient rows (trm_setup.h: build_down_rows); null / too wide for LDS: the generic kernel walks `fine`
     const float *rows;
     uint32_t lmax, rmax, pitch;
+    // Streaming (tiled kernel only): this launch converts a chunk of a longer utterance.  tube + tube_offset[v] then
+    // points at global tube sample n_origin (the chunk's history first), samples n_origin <= n < n_hi exist, and the
+    // launch emits outputs k_base <= k < k_end (global indices) at out + out_offset[v] + (k - k_base).  One-shot:
+    // stream = 0 and the bounds come from nframes.
+    int stream;
+    long long n_origin, n_hi;
+    uint32_t k_base, k_end;
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);

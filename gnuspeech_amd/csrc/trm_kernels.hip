@@ -484,11 +484,13 @@ __global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_d
     constexpr uint32_t kGroups = kDownVoices / kDownPerThread;
     const uint32_t tid = threadIdx.x, o = tid & (kDownCols - 1), w = tid / kDownCols;      // w: voice group 0..7
     const uint32_t pad = (uint32_t)C.padSize, inc = C.timeRegisterIncrement, CP = (uint32_t)C.controlPeriod;
-    const uint32_t k0 = blockIdx.x * kDownCols, v0 = blockIdx.y * kDownVoices;
+    const uint32_t k0 = D.k_base + blockIdx.x * kDownCols, v0 = blockIdx.y * kDownVoices;
+    // tube samples nOrg <= n < nOrg + sNt[voice] sit at tube + sOff[voice] (one-shot: the voice's own samples from 0)
+    const int64_t nOrg = D.stream ? (int64_t)D.n_origin : 0;
     if (tid < (uint32_t)kDownVoices) {
         const uint32_t vv = v0 + tid;
         const uint32_t nfr = vv < D.nvoices ? min(D.nframes[vv], D.max_nframes) : 0u;
-        sNt[tid] = nfr > 0 ? (nfr - 1) * CP : 0u;
+        sNt[tid] = D.stream ? (vv < D.nvoices ? (uint32_t)(D.n_hi - D.n_origin) : 0u) : (nfr > 0 ? (nfr - 1) * CP : 0u);
         sOff[tid] = vv < D.nvoices ? D.tube_offset[vv] : 0ull;
     }
     // the block's rows: output k0 + r has phase ((k0 + r) * inc) & 0xFFFF; 8 threads per row
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_d
         const float *src = D.tube + sOff[ww];
         const int64_t nt = (int64_t)sNt[ww];
         for (uint32_t i = tid & 7u; i < xlen; i += 8) {
-            const int64_t n = nLo + (int64_t)i;
+            const int64_t n = nLo + (int64_t)i - nOrg;
             sXw[ww * xlen + i] = (n >= 0 && n < nt) ? src[n] : 0.0f;
         }
     }
@@ -529,16 +531,17 @@ __global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_d
     for (int q = 0; q < kDownPerThread; q++) {
         const uint32_t wl = w + q * kGroups, v = v0 + wl;
         const bool voiced = v < D.nvoices && min(D.nframes[v < D.nvoices ? v : 0], D.max_nframes) > 0;
-        const uint32_t nout = voiced ? (uint32_t)((((uint64_t)sNt[wl] + 2ull * pad) * 65536ull + inc - 1) / inc) : 0u;
+        uint32_t nout = voiced ? (uint32_t)((((uint64_t)sNt[wl] + 2ull * pad) * 65536ull + inc - 1) / inc) : 0u;
+        if (D.stream) nout = v < D.nvoices ? D.k_end : 0u;
         float m = 0.0f;
         if (k < nout) {
-            (D.out + D.out_offset[v])[k] = acc[q];
+            (D.out + D.out_offset[v])[k - D.k_base] = acc[q];
             m = fabsf(acc[q]);
         }
         for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));     // the 32 lanes of this voice
         if (o == 0 && v < D.nvoices) {
             if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(&D.max_sample[v]), __float_as_uint(m));
-            if (blockIdx.x == 0) D.number_samples[v] = nout;
+            if (blockIdx.x == 0) D.number_samples[v] = nout - D.k_base;
         }
     }
 }
@@ -601,7 +604,8 @@ hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stre
     const size_t lds = ((size_t)kDownCols * (T | 1u) + (size_t)kDownVoices * xlen) * sizeof(float);
     if (a.rows && T > 0 && lds <= 48 * 1024) {
         const uint32_t ntubeMax = a.max_nframes > 0 ? (a.max_nframes - 1) * (uint32_t)c.controlPeriod : 0;
-        const uint64_t noutMax = (((uint64_t)ntubeMax + 2ull * (uint32_t)c.padSize) * 65536ull + c.timeRegisterIncrement - 1) / c.timeRegisterIncrement;
+        uint64_t noutMax = (((uint64_t)ntubeMax + 2ull * (uint32_t)c.padSize) * 65536ull + c.timeRegisterIncrement - 1) / c.timeRegisterIncrement;
+        if (a.stream) noutMax = a.k_end - a.k_base;
         hipError_t e = hipMemsetAsync(a.max_sample, 0, a.nvoices * sizeof(float), stream);
         if (e != hipSuccess) return e;
         const dim3 grid((unsigned)((noutMax + kDownCols - 1) / kDownCols > 0 ? (noutMax + kDownCols - 1) / kDownCols : 1),
@@ -609,6 +613,7 @@ hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stre
         hipLaunchKernelGGL(trm_downsample_rows_kernel, grid, dim3(kDownCols * kDownVoices / kDownPerThread), lds, stream, c, a, xlen);
         return hipGetLastError();
     }
+    if (a.stream) return hipErrorInvalidValue;       // (the generic kernel converts whole utterances only)
     hipLaunchKernelGGL(trm_downsample_kernel, dim3(a.nvoices), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }

@@ -63,6 +63,26 @@ def test_chunked_equals_one_shot(g, rate, chunks):
     assert np.allclose(got_max, mx, rtol=1e-4)
 
 
+@pytest.mark.parametrize("rate,chunks", [(16000.0, [5, 1, 1, 17, 2, 30, 4]), (8000.0, [60]), (16000.0, [1] * 12 + [48]),
+                                          (11025.0, [2, 58]), (8000.0, [3, 3, 1, 40, 13])])
+def test_chunked_equals_one_shot_downsampling(g, rate, chunks):
+    """The same invariants for output rates below the tube rate (19 750 Hz -> 16 / 11.025 / 8 kHz): the chunk's tube
+    samples go through HBM behind a history of 2*pad samples and the tiled down-sampling kernel converts the outputs
+    whose read position lies in the chunk."""
+    pd = cases.monet_default_params(rate)
+    V, n = 21, sum(chunks)
+    fr = cases.config3_frames(V, nframes=n).astype(np.float32)
+    whole, whole_max, _ = stream_all(g, pd, fr, [n])
+    got, got_max, _ = stream_all(g, pd, fr, chunks)
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+    assert np.array_equal(got_max, whole_max)
+    pcm, ns, mx = one_shot(g, pd, fr)
+    assert got.shape[1] == int(ns[0])
+    for v in range(V):
+        assert nrms(got[v], pcm[v], mx[v]) <= 2e-6, "voice %d" % v
+    assert np.allclose(got_max, mx, rtol=1e-4)
+
+
 def test_second_utterance_starts_from_rest(g):
     pd = cases.monet_default_params(44100.0)
     fr = cases.config3_frames(3, nframes=20).astype(np.float32)
