@@ -286,8 +286,9 @@ int  trm_batch_generate_frames_host(trm_batch *batch, const uint32_t *event_time
  * tube.c:2348-2420, Controller.m:73-100): shim/tract_tube.c implements tube.h's setters/getters over a
  * one-voice stream and pushes the current parameters every control period.
  *
- * All voices of a stream advance together (same number of frames per push).  Up-sampling voices only
- * (tube rate below the output rate: every shipped voice); the four-lane kernel form carries it. */
+ * All voices of a stream advance together (same number of frames per push).  Output rates above the tube rate
+ * (44.1 / 22.05 kHz for the shipped voices) and below it (16 / 8 kHz: the down-sampling branch) both stream; the
+ * four-lane kernel form carries it. */
 typedef struct trm_stream trm_stream;
 int  trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out);
 void trm_stream_destroy(trm_stream *stream);
