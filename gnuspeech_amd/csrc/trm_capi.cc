@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <thread>
@@ -196,16 +197,26 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dNoiseState, 2 * sizeof(double)));
     if (!c.upsample) {
-        std::vector<float> fine;
-        trm::build_src_fine(fine);
+        // host-side tables of the down-sampling branch, built once per process and ratio (a fresh tube per utterance,
+        // TRMSynthesizer.m:118-136, only uploads them)
+        static std::mutex mu;
+        static std::vector<float> fine;
+        struct DownRows { uint32_t phaseIncrement = 0; double ratio = 0.0; uint32_t l = 0, r = 0, pitch = 0; std::vector<float> rows; };
+        static DownRows cached;
+        std::lock_guard<std::mutex> lock(mu);
+        if (fine.empty()) trm::build_src_fine(fine);
         B_TRY(hipMalloc((void **)&b->dFine, fine.size() * sizeof(float)));
         B_TRY(hipMemcpy(b->dFine, fine.data(), fine.size() * sizeof(float), hipMemcpyHostToDevice));
         // rows of the tiled down-sampling kernel (launch_downsample falls back to walking `fine` when a row is too wide)
         if (c.phaseIncrement > 0 && trm::kSrcFineLen / c.phaseIncrement <= 160) {
-            std::vector<float> drows;
-            trm::build_down_rows(fine, c.sampleRateRatioD, c.phaseIncrement, b->downL, b->downR, b->downPitch, drows);
-            B_TRY(hipMalloc((void **)&b->dDownRows, drows.size() * sizeof(float)));
-            B_TRY(hipMemcpy(b->dDownRows, drows.data(), drows.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (cached.phaseIncrement != c.phaseIncrement || cached.ratio != c.sampleRateRatioD) {
+                trm::build_down_rows(fine, c.sampleRateRatioD, c.phaseIncrement, cached.l, cached.r, cached.pitch, cached.rows);
+                cached.phaseIncrement = c.phaseIncrement;
+                cached.ratio = c.sampleRateRatioD;
+            }
+            b->downL = cached.l; b->downR = cached.r; b->downPitch = cached.pitch;
+            B_TRY(hipMalloc((void **)&b->dDownRows, cached.rows.size() * sizeof(float)));
+            B_TRY(hipMemcpy(b->dDownRows, cached.rows.data(), cached.rows.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
 #undef B_TRY
@@ -259,24 +270,53 @@ size_t trm_samples_for_frames(const trm_input_params *params, size_t nframes)
 
 // The voice-independent noise sequence is generated on the device (fp64, one lane) and cached;
 // it only ever grows.  `need` = tube samples incl. the flush tail.
+// The low-passed noise sequence (TRMUtility.m:71-85, TRMFilters.m:81-86) depends on nothing: not on the voice, not on
+// the parameters, not on the device.  It is a serial fp64 recurrence (~55 ns per sample on one lane), so the process
+// generates each stretch of it once -- on whichever device first needs it -- keeps it on the host, and every batch
+// object uploads what it needs: a fresh tube per utterance (TRMSynthesizer.m:118-136) does not pay for it again.
+namespace {
+struct NoiseCache {
+    std::mutex mu;
+    std::vector<float> lp;
+    double state[2] = {0.7892347, 0.0};                                 // TRMUtility.m:72-77, TRMTubeModel.m:235
+};
+NoiseCache g_noise;
+}  // namespace
+
 static int ensure_noise(trm_batch *b, uint32_t need, hipStream_t stream)
 {
     if (need <= b->noiseLen) return TRM_OK;
-    uint32_t newLen = need + need / 2 + 4096;
+    const uint32_t newLen = need + need / 2 + 4096;
     if (newLen > b->dNoise.cap) {
-        // grow: regenerate from the start into a fresh buffer (serial recurrence, ~10 ns/sample)
+        // grow: a fresh buffer, refilled from the host copy below
         HIP_TRY(hipStreamSynchronize(stream));
         int rc = b->dNoise.reserve(newLen);
         if (rc) return rc;
         b->noiseLen = 0;
     }
-    if (b->noiseLen == 0) {
-        const double init[2] = {0.7892347, 0.0};                        // TRMUtility.m:72-77, TRMTubeModel.m:235
-        HIP_TRY(hipMemcpyAsync(b->dNoiseState, init, sizeof init, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));                          // init[] is a stack temporary
+    const uint32_t to = (uint32_t)b->dNoise.cap;
+    std::lock_guard<std::mutex> lock(g_noise.mu);
+    uint32_t have = (uint32_t)g_noise.lp.size();
+    if (have < to) {
+        // extend the process-wide sequence on this device, straight into this object's buffer, and take it home
+        HIP_TRY(hipMemcpyAsync(b->dNoiseState, g_noise.state, sizeof g_noise.state, hipMemcpyHostToDevice, stream));
+        HIP_TRY(trm::launch_noise(b->dNoise.p, have, to, b->dNoiseState, stream));
+        std::vector<float> fresh(to - have);
+        double st[2];
+        HIP_TRY(hipMemcpyAsync(fresh.data(), b->dNoise.p + have, fresh.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(st, b->dNoiseState, sizeof st, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        g_noise.lp.insert(g_noise.lp.end(), fresh.begin(), fresh.end());     // (only what was generated and fetched is remembered)
+        g_noise.state[0] = st[0];
+        g_noise.state[1] = st[1];
+    } else {
+        have = to;
     }
-    uint32_t to = (uint32_t)b->dNoise.cap;
-    HIP_TRY(trm::launch_noise(b->dNoise.p, b->noiseLen, to, b->dNoiseState, stream));
+    if (b->noiseLen < have) {
+        HIP_TRY(hipMemcpyAsync(b->dNoise.p + b->noiseLen, &g_noise.lp[b->noiseLen], (size_t)(have - b->noiseLen) * sizeof(float),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));                          // the host vector may grow (move) once the lock is gone
+    }
     b->noiseLen = to;
     return TRM_OK;
 }
