@@ -71,9 +71,10 @@ struct trm_batch {
     int device = 0;
     hipStream_t stream = nullptr;        // used by the host-buffer entry points
     trm::Const *dConst = nullptr;
-    float *dRowsAlloc = nullptr, *dRows = nullptr, *dSine = nullptr;
-    float *dFine = nullptr;              // down-sampling batches only
-    float *dDownRows = nullptr;          // down-sampling batches only: per-phase coefficient rows
+    // read-only tables shared per process and device (trm_batch_create): not owned
+    const float *dRows = nullptr, *dSine = nullptr;
+    const float *dFine = nullptr;        // down-sampling batches only
+    const float *dDownRows = nullptr;    // down-sampling batches only: per-phase coefficient rows
     uint32_t downL = 0, downR = 0, downPitch = 0;
     DevBuf<float> dTube;                 // down-sampling: tube-rate samples between the two kernels
     DevBuf<uint64_t> dTubeOff;
@@ -175,9 +176,6 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     // four SIMDs busy, so more voices run in rounds (measured on 256 CUs: 4096 voices 3.1 ms, 8192 6.2 ms, 12288
     // 9.0 ms) while the one-voice-per-lane form takes 7.1 ms for anything up to 16384 (profiles/sweep_forms_r01.txt).
     b->wideThreshold = 2u * 16u * (uint32_t)prop.multiProcessorCount + 1u;
-    std::vector<float> rows, sine;
-    trm::build_src_rows(rows);
-    trm::build_sine_table(sine);
     hipError_t e;
 #define B_TRY(expr)                                                              \
     if ((e = (expr)) != hipSuccess) {                                            \
@@ -187,36 +185,66 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipStreamCreate(&b->stream));
     B_TRY(hipMalloc((void **)&b->dConst, sizeof(trm::Const)));
     B_TRY(hipMemcpy(b->dConst, &b->c, sizeof(trm::Const), hipMemcpyHostToDevice));
-    // 4 zero floats in front of row 0: the convert stage fetches rows shifted by up to 3 floats
-    // [4 zeros in front of row 0: the shifted fetch of a row reads up to 3 floats before it][rows]
-    B_TRY(hipMalloc((void **)&b->dRowsAlloc, (rows.size() + 4) * sizeof(float)));
-    B_TRY(hipMemset(b->dRowsAlloc, 0, 4 * sizeof(float)));
-    b->dRows = b->dRowsAlloc + 4;
-    B_TRY(hipMemcpy(b->dRows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
-    B_TRY(hipMalloc((void **)&b->dSine, sine.size() * sizeof(float)));
-    B_TRY(hipMemcpy(b->dSine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dNoiseState, 2 * sizeof(double)));
-    if (!c.upsample) {
-        // host-side tables of the down-sampling branch, built once per process and ratio (a fresh tube per utterance,
-        // TRMSynthesizer.m:118-136, only uploads them)
+    {
+        // Read-only tables: built and uploaded once per process and device (per ratio for the down-sampling rows) and
+        // shared by every batch object there -- a fresh tube per utterance (TRMSynthesizer.m:118-136) finds them in place.
+        // They live as long as the process.
+        struct DeviceTables {
+            float *rows = nullptr, *sine = nullptr, *fine = nullptr;
+            struct Down { uint32_t phaseIncrement; double ratio; uint32_t l, r, pitch; float *rows; };
+            std::vector<Down> down;
+        };
         static std::mutex mu;
-        static std::vector<float> fine;
-        struct DownRows { uint32_t phaseIncrement = 0; double ratio = 0.0; uint32_t l = 0, r = 0, pitch = 0; std::vector<float> rows; };
-        static DownRows cached;
+        static std::vector<DeviceTables> tables;
+        static std::vector<float> hostFine;
         std::lock_guard<std::mutex> lock(mu);
-        if (fine.empty()) trm::build_src_fine(fine);
-        B_TRY(hipMalloc((void **)&b->dFine, fine.size() * sizeof(float)));
-        B_TRY(hipMemcpy(b->dFine, fine.data(), fine.size() * sizeof(float), hipMemcpyHostToDevice));
-        // rows of the tiled down-sampling kernel (launch_downsample falls back to walking `fine` when a row is too wide)
-        if (c.phaseIncrement > 0 && trm::kSrcFineLen / c.phaseIncrement <= 160) {
-            if (cached.phaseIncrement != c.phaseIncrement || cached.ratio != c.sampleRateRatioD) {
-                trm::build_down_rows(fine, c.sampleRateRatioD, c.phaseIncrement, cached.l, cached.r, cached.pitch, cached.rows);
-                cached.phaseIncrement = c.phaseIncrement;
-                cached.ratio = c.sampleRateRatioD;
+        if (tables.size() < (size_t)ndev) tables.resize(ndev);
+        DeviceTables &t = tables[device];
+        if (!t.rows) {
+            std::vector<float> rows, sine;
+            trm::build_src_rows(rows);
+            trm::build_sine_table(sine);
+            // [4 zeros in front of row 0: the convert stage's shifted fetch of a row reads up to 3 floats before it][rows]
+            float *alloc = nullptr;
+            B_TRY(hipMalloc((void **)&alloc, (rows.size() + 4) * sizeof(float)));
+            B_TRY(hipMemset(alloc, 0, 4 * sizeof(float)));
+            B_TRY(hipMemcpy(alloc + 4, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+            B_TRY(hipMalloc((void **)&t.sine, sine.size() * sizeof(float)));
+            B_TRY(hipMemcpy(t.sine, sine.data(), sine.size() * sizeof(float), hipMemcpyHostToDevice));
+            t.rows = alloc + 4;
+        }
+        b->dRows = t.rows;
+        b->dSine = t.sine;
+        if (!c.upsample) {
+            if (hostFine.empty()) trm::build_src_fine(hostFine);
+            if (!t.fine) {
+                float *p = nullptr;
+                B_TRY(hipMalloc((void **)&p, hostFine.size() * sizeof(float)));
+                B_TRY(hipMemcpy(p, hostFine.data(), hostFine.size() * sizeof(float), hipMemcpyHostToDevice));
+                t.fine = p;
             }
-            b->downL = cached.l; b->downR = cached.r; b->downPitch = cached.pitch;
-            B_TRY(hipMalloc((void **)&b->dDownRows, cached.rows.size() * sizeof(float)));
-            B_TRY(hipMemcpy(b->dDownRows, cached.rows.data(), cached.rows.size() * sizeof(float), hipMemcpyHostToDevice));
+            b->dFine = t.fine;
+            // rows of the tiled down-sampling kernel (launch_downsample falls back to walking `fine` when a row is too wide)
+            if (c.phaseIncrement > 0 && trm::kSrcFineLen / c.phaseIncrement <= 160) {
+                const DeviceTables::Down *hit = nullptr;
+                for (const auto &dn : t.down)
+                    if (dn.phaseIncrement == c.phaseIncrement && dn.ratio == c.sampleRateRatioD) hit = &dn;
+                if (!hit) {
+                    DeviceTables::Down dn;
+                    std::vector<float> drows;
+                    dn.phaseIncrement = c.phaseIncrement;
+                    dn.ratio = c.sampleRateRatioD;
+                    trm::build_down_rows(hostFine, dn.ratio, dn.phaseIncrement, dn.l, dn.r, dn.pitch, drows);
+                    dn.rows = nullptr;
+                    B_TRY(hipMalloc((void **)&dn.rows, drows.size() * sizeof(float)));
+                    B_TRY(hipMemcpy(dn.rows, drows.data(), drows.size() * sizeof(float), hipMemcpyHostToDevice));
+                    t.down.push_back(dn);
+                    hit = &t.down.back();
+                }
+                b->downL = hit->l; b->downR = hit->r; b->downPitch = hit->pitch;
+                b->dDownRows = hit->rows;
+            }
         }
     }
 #undef B_TRY
@@ -230,10 +258,6 @@ void trm_batch_destroy(trm_batch *b)
     (void)hipSetDevice(b->device);
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (b->dConst) (void)hipFree(b->dConst);
-    if (b->dRowsAlloc) (void)hipFree(b->dRowsAlloc);
-    if (b->dSine) (void)hipFree(b->dSine);
-    if (b->dFine) (void)hipFree(b->dFine);
-    if (b->dDownRows) (void)hipFree(b->dDownRows);
     if (b->dNoiseState) (void)hipFree(b->dNoiseState);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
