@@ -87,7 +87,9 @@ struct trm_batch {
     DevBuf<uint64_t> dFrameOff, dOutOff;
     DevBuf<uint32_t> dNFrames, dNSamples;
     // kernel timing (hipEvents on the launch stream)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;      // launches not yet folded into the sums below
+    double timedMs = 0.0;
+    uint32_t timedLaunches = 0;
     bool timing = true;
     int kernel = TRM_KERNEL_AUTO;        // trm_batch_set_kernel
     uint32_t wideThreshold = 4097;       // voices from which the one-voice-per-lane kernel is the faster form (set at create)
@@ -294,6 +296,26 @@ size_t trm_samples_for_frames(const trm_input_params *params, size_t nframes)
 
 // The voice-independent noise sequence is generated on the device (fp64, one lane) and cached;
 // it only ever grows.  `need` = tube samples incl. the flush tail.
+// Launch timing: finished launches (all of them when `wait`) leave the event list for the running sums.
+static int fold_events(trm_batch *b, bool wait)
+{
+    size_t done = 0;
+    for (auto &ev : b->events) {
+        if (wait) HIP_TRY(hipEventSynchronize(ev.second));
+        else if (hipEventQuery(ev.second) != hipSuccess) break;         // (in stream order: the later ones are not finished either)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+            b->timedMs += ms;
+            b->timedLaunches++;
+        }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+        done++;
+    }
+    b->events.erase(b->events.begin(), b->events.begin() + done);
+    return TRM_OK;
+}
+
 // The low-passed noise sequence (TRMUtility.m:71-85, TRMFilters.m:81-86) depends on nothing: not on the voice, not on
 // the parameters, not on the device.  It is a serial fp64 recurrence (~55 ns per sample on one lane), so the process
 // generates each stretch of it once -- on whichever device first needs it -- keeps it on the host, and every batch
@@ -403,6 +425,11 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     }
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EventGuard {     // the pair belongs to this call until it is handed to the batch's list
+        hipEvent_t &a, &b;
+        bool armed = true;
+        ~EventGuard() { if (armed) { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } }
+    } guard{e0, e1};
     if (b->timing) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
@@ -439,8 +466,12 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         HIP_TRY(trm::launch_downsample(b->c, d, stream));
     }
     if (b->timing) {
-        HIP_TRY(hipEventRecord(e1, stream));
-        b->events.emplace_back(e0, e1);
+        hipError_t e = hipEventRecord(e1, stream);
+        b->events.emplace_back(e0, e1);                 // (owned by the list from here on, whatever happened)
+        guard.armed = false;
+        if (e != hipSuccess) return fail(TRM_EHIP, "hipEventRecord: %s", hipGetErrorString(e));
+        // a caller that never asks for the time must not pile up events: fold the finished launches into the sums
+        if (b->events.size() >= 64) fold_events(b, false);
     }
     return TRM_OK;
 }
@@ -684,18 +715,12 @@ int trm_batch_last_kernel(const trm_batch *b) { return b ? b->lastKernel : TRM_K
 int trm_batch_kernel_time_ms(trm_batch *b, double *total_ms, uint32_t *launches)
 {
     if (!b || !total_ms || !launches) return fail(TRM_EINVAL, "null argument");
-    double sum = 0.0;
-    uint32_t n = 0;
-    for (auto &ev : b->events) {
-        HIP_TRY(hipEventSynchronize(ev.second));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
-        sum += ms;
-        n++;
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
-    b->events.clear();
+    int rc = fold_events(b, true);
+    if (rc) return rc;
+    const double sum = b->timedMs;
+    const uint32_t n = b->timedLaunches;
+    b->timedMs = 0.0;
+    b->timedLaunches = 0;
     *total_ms = sum;
     *launches = n;
     return TRM_OK;

@@ -466,6 +466,22 @@ def test_host_entry_int16(g, form, channels):
             assert np.array_equal(p16[v], ref), (wav, v)
 
 
+def test_launch_timing_is_bounded_and_complete(g):
+    """A caller that never asks for the kernel time must not pile up events: finished launches are folded into running
+    sums; asking later still accounts for every launch."""
+    import torch
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params(44100.0)))
+    st = b.prepare_device(cases.config2_frames(4, nframes=6))
+    b.kernel_time_ms()
+    for _ in range(300):
+        b.synthesize_device(st)
+    torch.cuda.synchronize()
+    t, n = b.kernel_time_ms()
+    assert n == 300 and t > 0.0
+    t, n = b.kernel_time_ms()
+    assert n == 0 and t == 0.0
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
