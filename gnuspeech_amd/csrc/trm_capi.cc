@@ -84,6 +84,11 @@ struct trm_batch {
     // host-form staging
     DevBuf<float> dFrames, dOut, dMax;
     DevBuf<int16_t> dOut16;
+    // trm_batch_generate_frames_host staging
+    DevBuf<uint32_t> evT, evN;
+    DevBuf<double> evV;
+    DevBuf<uint64_t> evOff;
+    DevBuf<float> evF;
     DevBuf<uint64_t> dFrameOff, dOutOff;
     DevBuf<uint32_t> dNFrames, dNSamples;
     // kernel timing (hipEvents on the launch stream)
@@ -977,10 +982,11 @@ int trm_batch_generate_frames_host(trm_batch *b, const uint32_t *times, const do
     if (want == 0) return TRM_OK;
     if (!frames_out || frames_cap < want) return fail(TRM_EINVAL, "frame buffer holds %zu rows, %zu needed", frames_cap, want);
     HIP_TRY(hipSetDevice(b->device));
-    DevBuf<uint32_t> dT, dN;
-    DevBuf<double> dV;
-    DevBuf<uint64_t> dOff;
-    DevBuf<float> dF;
+    // staging buffers of this entry live in the batch object (grow-only): no allocation per utterance
+    DevBuf<uint32_t> &dT = b->evT, &dN = b->evN;
+    DevBuf<double> &dV = b->evV;
+    DevBuf<uint64_t> &dOff = b->evOff;
+    DevBuf<float> &dF = b->evF;
     if ((rc = dT.reserve(nevents)) || (rc = dV.reserve(nevents * TRM_EVENT_VALUES)) || (rc = dOff.reserve(2)) || (rc = dN.reserve(2)) ||
         (rc = dF.reserve(want * 16)))
         return rc;
