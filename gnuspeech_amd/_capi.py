@@ -54,7 +54,7 @@ class TrmDerived(C.Structure):
 # every symbol include/trm_c_api.h declares
 EXPORTS = [
     "trm_strerror", "trm_last_error", "trm_data_list_read_file", "trm_data_list_write_file", "trm_free",
-    "trm_tube_create", "trm_tube_destroy", "trm_tube_derived", "trm_tube_synthesize",
+    "trm_tube_create", "trm_tube_destroy", "trm_tube_derived", "trm_tube_print_input_data", "trm_tube_synthesize",
     "trm_tube_number_samples", "trm_tube_maximum_sample_value", "trm_tube_samples",
     "trm_tube_save_output_to_file", "trm_tube_generate_wav_data", "trm_write_sound_file",
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
@@ -106,6 +106,7 @@ def lib():
     L.trm_tube_destroy.argtypes = [vp]
     L.trm_tube_derived.argtypes = [vp, C.POINTER(TrmDerived)]
     L.trm_tube_synthesize.argtypes = [vp, C.POINTER(TrmParameters), C.c_size_t]
+    L.trm_tube_print_input_data.argtypes = [vp, C.POINTER(TrmParameters), C.c_size_t]
     L.trm_tube_number_samples.argtypes = [vp]
     L.trm_tube_number_samples.restype = C.c_size_t
     L.trm_tube_maximum_sample_value.argtypes = [vp]

@@ -1084,6 +1084,57 @@ size_t trm_tube_number_samples(const trm_tube *t) { return t ? t->numberSamples 
 double trm_tube_maximum_sample_value(const trm_tube *t) { return t ? (double)t->maxSample : 0.0; }
 const float *trm_tube_samples(const trm_tube *t) { return (t && !t->samples.empty()) ? t->samples.data() : nullptr; }
 
+int trm_tube_print_input_data(const trm_tube *t, const trm_parameters *frames, size_t nframes)
+{
+    if (!t || (nframes && !frames)) return fail(TRM_EINVAL, "null argument");
+    const trm_input_params &p = t->b->params;
+    // -[TRMDataList printInputParameters], TRMDataList.m:251-283
+    static const char *const fmtName[] = {"AU", "AIFF", "WAVE"};
+    printf("outputFileFormat:\t%s\n", (p.outputFileFormat >= 0 && p.outputFileFormat <= 2) ? fmtName[p.outputFileFormat] : "Unknown");
+    printf("outputRate:\t\t%.1f Hz\n", p.outputRate);
+    printf("controlRate:\t\t%.2f Hz\n\n", p.controlRate);
+    printf("volume:\t\t\t%.2f dB\n", p.volume);
+    printf("channels:\t\t%-lu\n", (unsigned long)p.channels);
+    printf("balance:\t\t%+1.2f\n\n", p.balance);
+    printf("waveform:\t\t%s\n", p.waveform == 0 ? "Pulse" : p.waveform == 1 ? "Sine" : "Unknown");
+    printf("tp:\t\t\t%.2f%%\n", p.tp);
+    printf("tnMin:\t\t\t%.2f%%\n", p.tnMin);
+    printf("tnMax:\t\t\t%.2f%%\n", p.tnMax);
+    printf("breathiness:\t\t%.2f%%\n\n", p.breathiness);
+    printf("nominal tube length:\t%.2f cm\n", p.length);
+    printf("temperature:\t\t%.2f degrees C\n", p.temperature);
+    printf("lossFactor:\t\t%.2f%%\n\n", p.lossFactor);
+    printf("apScale:\t\t%.2f cm\n", p.apScale);
+    printf("mouthCoef:\t\t%.1f Hz\n", p.mouthCoef);
+    printf("noseCoef:\t\t%.1f Hz\n\n", p.noseCoef);
+    for (long i = 1; i < TRM_TOTAL_NASAL_SECTIONS; i++) printf("n%-ld:\t\t\t%.2f cm\n", i, p.noseRadius[i]);
+    printf("\nthroatCutoff:\t\t%.1f Hz\n", p.throatCutoff);
+    printf("throatVol:\t\t%.2f dB\n\n", p.throatVol);
+    printf("modulation:\t\t");
+    printf("%s\n", p.usesModulation ? "on" : "off");
+    printf("mixOffset:\t\t%.2f dB\n\n", p.mixOffset);
+    // derived values, TRMTubeModel.m:599-602
+    const trm_derived &d = t->b->d;
+    printf("\nactual tube length:\t%.4f cm\n", d.actualTubeLength);
+    printf("internal sample rate:\t%-d Hz\n", d.sampleRate);
+    printf("control period:\t\t%-d samples (%.4f seconds)\n\n", d.controlPeriod, (float)d.controlPeriod / (float)d.sampleRate);
+    // -[TRMDataList printControlRateInputTable], TRMDataList.m:294-330
+    printf("\n%-lu control rate input tables:\n\n", (unsigned long)nframes);
+    printf("glPitch\tglotVol\taspVol\tfricVol\tfricPos\tfricCF\tfricBW");
+    for (unsigned long i = 0; i < TRM_TOTAL_REGIONS; i++) printf("\tr%-lu", i + 1);
+    printf("\tvelum\n");
+    for (size_t f = 0; f < nframes; f++) {
+        const trm_parameters &q = frames[f];
+        printf("%.2f\t%.2f\t%.2f\t%.2f\t%.2f\t%.2f\t%.2f", q.glottalPitch, q.glottalVolume, q.aspirationVolume, q.fricationVolume,
+               q.fricationPosition, q.fricationCenterFrequency, q.fricationBandwidth);
+        for (int i = 0; i < TRM_TOTAL_REGIONS; i++) printf("\t%.2f", q.radius[i]);
+        printf("\t%.2f\n", q.velum);
+    }
+    printf("\n");
+    fflush(stdout);
+    return TRM_OK;
+}
+
 int trm_tube_save_output_to_file(trm_tube *t, const char *filename)
 {
     if (!t || !filename) return fail(TRM_EINVAL, "null argument");

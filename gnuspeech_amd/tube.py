@@ -142,6 +142,15 @@ class TRMTubeModel:
         check(lib().trm_tube_derived(self._h, C.byref(d)))
         return {k: getattr(d, k) for k, _ in TrmDerived._fields_}
 
+    def printInputData(self):                    # TRMTubeModel.m:595-605, to stdout like the reference
+        import sys
+        sys.stdout.flush()
+        fr = self.inputData.frame_array()
+        buf = (TrmParameters * max(1, fr.shape[0]))()
+        if fr.shape[0]:
+            C.memmove(buf, fr.ctypes.data, fr.nbytes)
+        check(lib().trm_tube_print_input_data(self._h, buf, fr.shape[0]))
+
     def synthesize(self):
         fr = self.inputData.frame_array()
         buf = (TrmParameters * max(1, fr.shape[0]))()

@@ -127,6 +127,10 @@ int  trm_tube_create(const trm_input_params *params, int device, trm_tube **tube
 void trm_tube_destroy(trm_tube *tube);
 int  trm_tube_derived(const trm_tube *tube, trm_derived *out);
 
+/* -printInputData (TRMTubeModel.m:595-605): -[TRMDataList printInputParameters] (TRMDataList.m:251-292), the three derived
+ * values, -[TRMDataList printControlRateInputTable] (TRMDataList.m:294-330), to stdout in the reference's formats. */
+int  trm_tube_print_input_data(const trm_tube *tube, const trm_parameters *frames, size_t nframes);
+
 /* -synthesize (TRMTubeModel.m:272-361) over inputData.values = frames[0..nframes):
  * N frames -> N-1 control periods; 0 frames is a silent no-op (:274-277). */
 int  trm_tube_synthesize(trm_tube *tube, const trm_parameters *frames, size_t nframes);

@@ -307,6 +307,47 @@ def test_cli_batch_directory_equals_single_file_mode(g, tmp_path):
         assert open(single, "rb").read() == open(str(out_b / (name[:-4] + ext)), "rb").read()
 
 
+def test_cli_verbose_prints_input_data_like_the_reference(g, tmp_path):
+    """softwareTRM -v (Frameworks/Tube/main.m:44-64): -printInputData's text (TRMDataList.m:251-330,
+    TRMTubeModel.m:599-602) in the reference's formats, then the progress lines."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pd = cases.monet_default_params(22050.0)
+    pd.update(outputFileFormat=2, channels=2, balance=-0.25, volume=57.5)
+    rows = cases.load_gnuspeech_rows()[30:33]
+    dl = g.TRMDataList()
+    dl.inputParameters = g.TRMInputParameters.from_dict(pd)
+    dl.values = [g.TRMParameters(r) for r in rows]
+    inp, out = str(tmp_path / "a.trm"), str(tmp_path / "a.wav")
+    dl.writeToFile(inp)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "softwaretrm.py"), "-v", inp, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    back = g.TRMDataList.initWithContentsOfFile(inp)           # (the file path doubles the last row, TRMDataList.m:239-241)
+    p = back.inputParameters
+    d = g.TRMTubeModel.initWithInputData(back).derived()
+    exp = "input file:\t\t%s\n\n" % inp
+    exp += "outputFileFormat:\tWAVE\noutputRate:\t\t%.1f Hz\ncontrolRate:\t\t%.2f Hz\n\n" % (p.outputRate, p.controlRate)
+    exp += "volume:\t\t\t%.2f dB\nchannels:\t\t%d\nbalance:\t\t%+1.2f\n\n" % (p.volume, p.channels, p.balance)
+    exp += "waveform:\t\tPulse\ntp:\t\t\t%.2f%%\ntnMin:\t\t\t%.2f%%\ntnMax:\t\t\t%.2f%%\nbreathiness:\t\t%.2f%%\n\n" % (p.tp, p.tnMin, p.tnMax, p.breathiness)
+    exp += "nominal tube length:\t%.2f cm\ntemperature:\t\t%.2f degrees C\nlossFactor:\t\t%.2f%%\n\n" % (p.length, p.temperature, p.lossFactor)
+    exp += "apScale:\t\t%.2f cm\nmouthCoef:\t\t%.1f Hz\nnoseCoef:\t\t%.1f Hz\n\n" % (p.apScale, p.mouthCoef, p.noseCoef)
+    exp += "".join("n%d:\t\t\t%.2f cm\n" % (i, p.noseRadius[i]) for i in range(1, 6))
+    exp += "\nthroatCutoff:\t\t%.1f Hz\nthroatVol:\t\t%.2f dB\n\nmodulation:\t\t%s\nmixOffset:\t\t%.2f dB\n\n" % (
+        p.throatCutoff, p.throatVol, "on" if p.usesModulation else "off", p.mixOffset)
+    exp += "\nactual tube length:\t%.4f cm\ninternal sample rate:\t%d Hz\ncontrol period:\t\t%d samples (%.4f seconds)\n\n" % (
+        d["actualTubeLength"], d["sampleRate"], d["controlPeriod"], np.float32(d["controlPeriod"]) / np.float32(d["sampleRate"]))
+    fr = back.frame_array()
+    exp += "\n%d control rate input tables:\n\n" % len(fr)
+    exp += "glPitch\tglotVol\taspVol\tfricVol\tfricPos\tfricCF\tfricBW" + "".join("\tr%d" % (i + 1) for i in range(8)) + "\tvelum\n"
+    for row in fr:
+        exp += "\t".join("%.2f" % x for x in row) + "\n"
+    exp += "\n\nCalculating floating point samples...\nStarting synthesis\ndone.\n"
+    assert r.stdout.startswith(exp), "\n".join(a + "   |   " + b for a, b in zip(r.stdout.splitlines(), exp.splitlines()) if a != b)
+    assert r.stdout.rstrip().endswith("Wrote scaled samples to file:  %s" % out)
+
+
 def test_device_path_and_int16(g, form):
     """Device-buffer entry (what bench.py times) == host-buffer entry; int16 normalisation on device."""
     import torch

@@ -61,12 +61,11 @@ def main(argv):
     if tube is None:
         sys.stderr.write("Aborting...\n")
         return 255
-    if verbose:
+    if verbose:                                               # main.m:44-51
         print("input file:\t\t%s\n" % inp)
-        d = tube.derived()
-        print("actual tube length:\t%.4f cm\ninternal sample rate:\t%d Hz\ncontrol period:\t\t%d samples" % (
-            d["actualTubeLength"], d["sampleRate"], d["controlPeriod"]))
+        tube.printInputData()
         print("\nCalculating floating point samples...\nStarting synthesis")
+        sys.stdout.flush()
     tube.synthesize()
     if verbose:
         print("done.")
