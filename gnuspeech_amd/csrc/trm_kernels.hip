@@ -436,10 +436,14 @@ __global__ __launch_bounds__(256) void trm_downsample_kernel(const Const C, cons
     const uint32_t ntube = nfr > 0 ? (nfr - 1) * (uint32_t)C.controlPeriod : 0;
     const uint32_t inc = C.timeRegisterIncrement;
     uint32_t nout = 0;
-    if (nfr > 0) nout = (uint32_t)((((uint64_t)ntube + 2ull * pad) * 65536ull + inc - 1) / inc);
+    if (nfr > 0) nout = (uint32_t)src_count_outputs(ntube, pad, inc);
     const float *x = D.tube + D.tube_offset[v];
     float *out = D.out + D.out_offset[v];
-    auto sample = [&](int64_t n) { return (n >= 0 && n < (int64_t)ntube) ? x[n] : 0.0f; };
+    const int64_t total = (int64_t)ntube + 2 * (int64_t)pad;
+    auto sample = [&](int64_t n) {
+        n = src_ring_sample(n, total);
+        return (n >= 0 && n < (int64_t)ntube) ? x[n] : 0.0f;
+    };
     float m = 0.0f;
     for (uint32_t k = threadIdx.x; k < nout; k += blockDim.x) {
         const uint64_t tk = (uint64_t)k * inc;
@@ -505,7 +509,8 @@ __global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_d
         const float *src = D.tube + sOff[ww];
         const int64_t nt = (int64_t)sNt[ww];
         for (uint32_t i = tid & 7u; i < xlen; i += 8) {
-            const int64_t n = nLo + (int64_t)i - nOrg;
+            int64_t n = nLo + (int64_t)i - nOrg;
+            if (!D.stream) n = src_ring_sample(n, nt + 2 * (int64_t)pad);      // (one-shot: nt = the voice's tube samples)
             sXw[ww * xlen + i] = (n >= 0 && n < nt) ? src[n] : 0.0f;
         }
     }
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_d
     for (int q = 0; q < kDownPerThread; q++) {
         const uint32_t wl = w + q * kGroups, v = v0 + wl;
         const bool voiced = v < D.nvoices && min(D.nframes[v < D.nvoices ? v : 0], D.max_nframes) > 0;
-        uint32_t nout = voiced ? (uint32_t)((((uint64_t)sNt[wl] + 2ull * pad) * 65536ull + inc - 1) / inc) : 0u;
+        uint32_t nout = voiced ? (uint32_t)src_count_outputs(sNt[wl], pad, inc) : 0u;
         if (D.stream) nout = v < D.nvoices ? D.k_end : 0u;
         float m = 0.0f;
         if (k < nout) {
@@ -604,7 +609,8 @@ hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stre
     const size_t lds = ((size_t)kDownCols * (T | 1u) + (size_t)kDownVoices * xlen) * sizeof(float);
     if (a.rows && T > 0 && lds <= 48 * 1024) {
         const uint32_t ntubeMax = a.max_nframes > 0 ? (a.max_nframes - 1) * (uint32_t)c.controlPeriod : 0;
-        uint64_t noutMax = (((uint64_t)ntubeMax + 2ull * (uint32_t)c.padSize) * 65536ull + c.timeRegisterIncrement - 1) / c.timeRegisterIncrement;
+        // (a shorter voice may end on the reference's extra lap, src_count_outputs: cover it)
+        uint64_t noutMax = (((uint64_t)ntubeMax + 2ull * (uint32_t)c.padSize + kSrcRing) * 65536ull + c.timeRegisterIncrement - 1) / c.timeRegisterIncrement;
         if (a.stream) noutMax = a.k_end - a.k_base;
         hipError_t e = hipMemsetAsync(a.max_sample, 0, a.nvoices * sizeof(float), stream);
         if (e != hipSuccess) return e;

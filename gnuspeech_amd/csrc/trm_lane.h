@@ -583,6 +583,36 @@ TRM_HD float src_dot32(const float *w, const float *c)
 // Converter bookkeeping in closed form (TRMSampleRateConverter.m:221-232): output k sits at input
 // time k*inc (16.16 fixed point): phase = low 16 bits, read position e = high part.
 TRM_HD uint32_t src_phase(uint32_t k, uint32_t inc) { return (k * inc) & 0xFFFFu; }
+// Outputs of a voice of `ntube` tube samples: output k sits at input time k*inc and is produced while its read
+// position floor(k*inc / 2^16) lies before the end of the data, ntube + 2*pad with the flush's zeros
+// (TRMSampleRateConverter.m:160-173, TRMRingBuffer.m:85-93).  One reference behaviour belongs to the count: when
+// DOWN-sampling (inc > 2^16) the read position advances by more than one sample per output, so a dataEmpty can stop
+// one or two samples PAST its end pointer; if the flush's final dataEmpty then finds its own end pointer at or behind
+// that position -- the data ended within a sample or two after a multiple of the ring's fill size, 1024 - 2*pad, where
+// the previous dataEmpty ran -- it takes the end pointer for wrapped (:160-163) and converts one more lap of the ring:
+// 1024 further input positions whose samples are whatever the ring still holds (src_ring_sample below).
+constexpr uint32_t kSrcRing = 1024;        // TRMRingBuffer.h BUFFER_SIZE
+TRM_HD uint64_t src_count_outputs(uint64_t ntube, uint32_t pad, uint32_t inc)
+{
+    const uint64_t total = ntube + 2ull * pad;
+    if (inc > 65536u) {
+        const uint64_t fill = kSrcRing - 2ull * pad;
+        if (total >= fill) {
+            const uint64_t prevEnd = (total / fill) * fill;                     // where the dataEmpty before the last one ended
+            const uint64_t k = (prevEnd * 65536ull + inc - 1) / inc;            // the first output it left for the last one
+            if (((k * inc) >> 16) > total) return ((total + kSrcRing) * 65536ull + inc - 1) / inc;
+        }
+    }
+    return (total * 65536ull + inc - 1) / inc;
+}
+// What the converter finds at tube-sample index n (n = ring position - pad) of a voice whose ring received `total` samples
+// (the flush's zeros included): past the last one the ring still holds the sample written one lap earlier.
+TRM_HD long long src_ring_sample(long long n, long long total)
+{
+    while (n >= total) n -= (long long)kSrcRing;
+    return n;
+}
+
 TRM_HD uint32_t src_position(uint32_t k, uint32_t inc) { return (uint32_t)(((uint64_t)k * inc) >> 16); }
 
 }  // namespace trm

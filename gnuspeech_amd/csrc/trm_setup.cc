@@ -187,11 +187,7 @@ void build_sine_table(std::vector<float> &tab)
 
 uint64_t count_outputs(const trm_derived &d, uint64_t ntube)
 {
-    // output k sits at input time k*inc (16.16); it is produced while floor(k*inc/65536) <
-    // ntube + 2*pad (TRMSampleRateConverter.m:160-173 with the 2*pad zero flush, TRMRingBuffer.m:85-93)
-    uint64_t total = ntube + 2ull * (uint64_t)d.padSize;
-    uint64_t inc = d.timeRegisterIncrement;
-    return (total * 65536ull + inc - 1) / inc;
+    return src_count_outputs(ntube, (uint32_t)d.padSize, d.timeRegisterIncrement);      // trm_lane.h: the kernels use the same function
 }
 
 int build_const(const trm_input_params &p, Const &c, trm_derived &d)

@@ -154,6 +154,29 @@ def test_downsampling_speech_rates(g, form, rate, monkeypatch):
         assert np.array_equal(a, c)
 
 
+def test_downsampling_reference_extra_lap(g, form, monkeypatch):
+    """The reference's down-sampling converter can end an utterance with one more lap of its ring (the last dataEmpty
+    finds its end pointer behind the read position and takes it for wrapped, TRMSampleRateConverter.m:160-163 after
+    TRMRingBuffer.m:85-93): ~600 further outputs computed from what the ring still holds.  Part of the reference's
+    result, so part of ours: 1137 frames at 11.025 kHz hit it, 1136 do not."""
+    from gnuspeech_amd import shard
+    pd = cases.monet_default_params(11025.0)
+    ip = g.TRMInputParameters.from_dict(pd)
+    d = shard.derive(ip)
+    plain = lambda n: (((n - 1) * d["controlPeriod"] + 2 * d["padSize"]) * 65536 + d["timeRegisterIncrement"] - 1) // d["timeRegisterIncrement"]
+    assert shard.samples_for_frames(ip, 1137) == plain(1137) + 572 and shard.samples_for_frames(ip, 1136) == plain(1136)
+    rows = cases.load_gnuspeech_rows()
+    long_rows = np.concatenate([rows] * 4)
+    voices = [long_rows[:1137].copy(), long_rows[100:1236].copy(), long_rows[7:1144].copy()]
+    _batch_vs_oracle(g, pd, voices)                                   # counts exact, RMS within tolerance, incl. the extra lap
+    b = g.TRMBatch(ip)
+    pcm, ns, mx = b.synthesize(voices)
+    assert [int(x) for x in ns] == [plain(1137) + 572, plain(1136), plain(1137) + 572]
+    monkeypatch.setenv("TRM_DOWNSAMPLE_GENERIC", "1")                 # the generic kernel: the same bits
+    pcm2, ns2, mx2 = b.synthesize(voices)
+    assert np.array_equal(ns, ns2) and np.array_equal(mx, mx2) and all(np.array_equal(a, c) for a, c in zip(pcm, pcm2))
+
+
 def test_extreme_rate_ratios(g, form):
     """Converter ratios at both ends of the up-sampling range: a 30 cm tube (tube rate ~11.7 kHz, ratio 3.8 at
     44.1 kHz: the converter produces ~15 outputs per pipeline step) and a 15.8 cm tube at 22.05 kHz (ratio 1.008)."""
