@@ -301,6 +301,8 @@ size_t trm_samples_for_frames(const trm_input_params *params, size_t nframes)
 
 // The voice-independent noise sequence is generated on the device (fp64, one lane) and cached;
 // it only ever grows.  `need` = tube samples incl. the flush tail.
+static bool quad_ratio_too_high(const trm::Const &c) { return c.upsample && c.timeRegisterIncrement < 65536u / 4u; }
+
 // Launch timing: finished launches (all of them when `wait`) leave the event list for the running sums.
 static int fold_events(trm_batch *b, bool wait)
 {
@@ -448,6 +450,11 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         if (const char *e = getenv("TRM_TUBE_KERNEL")) which = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : which;
     }
     if (which == TRM_KERNEL_AUTO) which = nvoices >= (size_t)b->wideThreshold ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD;
+    // The four-lane form's converter is fed one block of coefficient rows per step by design (two at a push): four
+    // outputs per tube sample.  It measured clean to 5.3 and wrong from 5.6 on (the ring laps the converter;
+    // tools/fuzz_parity.py at 96 kHz), so above 4 -- 96 kHz output from any adult tube, 64 kHz from 22 cm on -- the
+    // one-voice-per-lane form runs, whatever was asked for.
+    if (which == TRM_KERNEL_QUAD && quad_ratio_too_high(b->c)) which = TRM_KERNEL_WIDE;
     b->lastKernel = which;
     if (which == TRM_KERNEL_QUAD)
         HIP_TRY(trm::launch_tube_quad(b->c, a, stream));
@@ -509,6 +516,10 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
         // (a chunk emits the outputs whose read position lies inside it; their right wing must end there too)
         trm_batch_destroy(b);
         return fail(TRM_ERANGE, "streaming: output rate too far below the tube rate (%d Hz) for the tiled down-sampling kernel", b->d.sampleRate);
+    }
+    if (quad_ratio_too_high(b->c)) {
+        trm_batch_destroy(b);
+        return fail(TRM_ERANGE, "streaming: more than four outputs per tube sample (tube rate %d Hz): the four-lane kernel form that carries streams does not convert that", b->d.sampleRate);
     }
     trm_stream *s = new (std::nothrow) trm_stream();
     if (!s) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_stream"); }

@@ -315,7 +315,8 @@ int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_
  *                    the chip (AUTO: above 32 voices per CU, 8192 on MI355X);
  *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: lowest latency for smaller batches.
  * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad
- * overrides AUTO (diagnostics).  No reference counterpart: the reference runs one tube per thread. */
+ * overrides AUTO (diagnostics).  Parameters with more than four output samples per tube sample (96 kHz output)
+ * always run TRM_KERNEL_WIDE.  No reference counterpart: the reference runs one tube per thread. */
 enum { TRM_KERNEL_AUTO = 0, TRM_KERNEL_WIDE = 1, TRM_KERNEL_QUAD = 2 };
 int  trm_batch_set_kernel(trm_batch *batch, int kernel);
 int  trm_batch_last_kernel(const trm_batch *batch);

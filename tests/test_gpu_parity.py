@@ -177,6 +177,20 @@ def test_downsampling_reference_extra_lap(g, form, monkeypatch):
     assert np.array_equal(ns, ns2) and np.array_equal(mx, mx2) and all(np.array_equal(a, c) for a, c in zip(pcm, pcm2))
 
 
+def test_very_high_rate_ratio_runs_the_lane_form(g, form):
+    """96 kHz output from a 26 cm tube: 7.2 outputs per tube sample, more than the four-lane form's converter is fed
+    for; the library runs the one-voice-per-lane form whatever was asked for, and a stream is refused."""
+    pd = cases.monet_default_params(96000.0)
+    pd["length"] = 26.0
+    rows = cases.load_gnuspeech_rows()
+    _batch_vs_oracle(g, pd, [rows[:120].copy(), rows[50:343].copy(), rows[5:6].copy()])
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    b.synthesize([rows[:30].copy()])
+    assert b.last_kernel == "wide"
+    with pytest.raises(g.TrmError):
+        g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=1)
+
+
 def test_extreme_rate_ratios(g, form):
     """Converter ratios at both ends of the up-sampling range: a 30 cm tube (tube rate ~11.7 kHz, ratio 3.8 at
     44.1 kHz: the converter produces ~15 outputs per pipeline step) and a 15.8 cm tube at 22.05 kHz (ratio 1.008)."""

@@ -12,7 +12,7 @@ maxframes = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 bad = 0
 for seed in range(first, last):
     rng = np.random.default_rng(5000 + seed)
-    pd = cases.monet_default_params(float(rng.choice([22050.0, 44100.0, 16000.0, 8000.0, 11025.0, 48000.0])))
+    pd = cases.monet_default_params(float(rng.choice([22050.0, 44100.0, 16000.0, 8000.0, 11025.0, 48000.0, 32000.0, 12000.0, 96000.0])))
     pd.update(controlRate=float(rng.choice([100.0, 250.0, 500.0, 1000.0])), waveform=int(rng.integers(0, 2)),
               tp=float(rng.uniform(20, 45)), tnMin=float(rng.uniform(8, 20)), breathiness=float(rng.uniform(0, 10)),
               length=float(rng.uniform(10.0, 30.0)), temperature=float(rng.uniform(25, 40)), lossFactor=float(rng.uniform(0.1, 3.0)),
