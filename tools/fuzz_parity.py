@@ -9,6 +9,7 @@ import cases, oracle_lib as O
 import gnuspeech_amd as g
 first, last = int(sys.argv[1]), int(sys.argv[2])
 maxframes = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+broad = len(sys.argv) > 4 and sys.argv[4] == "broad"        # wider (still legal) parameter and track ranges
 bad = 0
 for seed in range(first, last):
     rng = np.random.default_rng(5000 + seed)
@@ -20,11 +21,20 @@ for seed in range(first, last):
               noseRadius=[0.0] + [float(x) for x in rng.uniform(0.5, 2.5, 5)], throatCutoff=float(rng.uniform(500, 3000)),
               throatVol=float(rng.uniform(0, 24)), usesModulation=int(rng.integers(0, 2)), mixOffset=float(rng.uniform(30, 60)))
     pd["tnMax"] = pd["tnMin"] + float(rng.uniform(5, 20))
+    if broad:
+        pd.update(controlRate=float(rng.choice([50.0, 125.0, 250.0, 333.0, 800.0, 1500.0])), tp=float(rng.uniform(5, 60)),
+                  tnMin=float(rng.uniform(2, 20)), breathiness=float(rng.uniform(0, 40)), temperature=float(rng.uniform(10, 45)),
+                  lossFactor=float(rng.uniform(0.0, 5.0)), apScale=float(rng.uniform(0.8, 8.0)), mouthCoef=float(rng.uniform(500, 9000)),
+                  noseCoef=float(rng.uniform(500, 9000)), throatCutoff=float(rng.uniform(100, 8000)), throatVol=float(rng.uniform(0, 48)),
+                  mixOffset=float(rng.uniform(10, 60)), noseRadius=[0.0] + [float(x) for x in rng.uniform(0.1, 3.0, 5)])
+        pd["tnMax"] = pd["tnMin"] + float(rng.uniform(1, 35))
     voices = []
     for _ in range(int(rng.integers(1, 24))):
         n = int(rng.integers(0, maxframes)); knots = max(2, n // 8); t = np.linspace(0, knots - 1, max(n, 1))
         def track(lo, hi): return np.interp(t, np.arange(knots), rng.uniform(lo, hi, knots))
         fr = np.stack([track(-10, 6), track(0, 60), track(0, 20), track(0, 40), track(0, 7), track(500, 5000), track(200, 2500)] + [track(0.05, 2.5) for _ in range(8)] + [track(0.0, 1.2)], axis=1)
+        if broad:
+            fr = np.stack([track(-24, 24), track(0, 70), track(0, 45), track(0, 70), track(0, 7.999), track(100, 12000), track(50, 6000)] + [track(0.01, 3.0) for _ in range(8)] + [track(0.0, 2.0)], axis=1)
         voices.append(fr[:n])
     op = O.InputParams.from_dict(pd)
     ref = [O.synthesize(op, np.asarray(v, np.float32).astype(np.float64)) for v in voices]
