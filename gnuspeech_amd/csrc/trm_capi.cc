@@ -123,7 +123,7 @@ const char *trm_strerror(int code)
     case TRM_EIO: return "file i/o error";
     case TRM_EPARSE: return "truncated input file";
     case TRM_ESILENT: return "maximum sample value is zero";
-    case TRM_ERANGE: return "rates outside the supported range";
+    case TRM_ERANGE: return "parameters outside the supported range";
     }
     return "unknown";
 }

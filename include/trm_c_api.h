@@ -42,7 +42,7 @@ enum {
     TRM_EIO            = 7,   /* file open / read / write   (TRMDataList.m:45-49 -> NO)       */
     TRM_EPARSE         = 8,   /* truncated utterance-rate header (TRMDataList.m:53-214)      */
     TRM_ESILENT        = 9,   /* maximumSampleValue == 0    (TRMTubeModel.m:511 assert)       */
-    TRM_ERANGE         = 10   /* rates outside what the kernels support     */
+    TRM_ERANGE         = 10   /* rates or glottal-pulse shape (tp + tnMax > 100 %) outside what is supported */
 };
 
 /* TRMInputParameters (Frameworks/Tube/TRMInputParameters.h:26-54): the 26 utterance-rate

@@ -362,6 +362,9 @@ static int tube_init(tube_t *t, const trm_input_params *p, trm_derived *d)
     t->firPtr = 0;
     t->tableDiv1 = (int32_t)rint(WT_LEN * (p->tp / 100.0));
     t->tableDiv2 = (int32_t)rint(WT_LEN * ((p->tp + p->tnMax) / 100.0));
+    /* (the reference does not check: tp + tnMax above 100 % makes it write past its 512-entry table, TRMWavetable.m:86-96;
+       the library refuses such parameters with TRM_ERANGE, and so does this restatement) */
+    if (t->tableDiv1 < 0 || t->tableDiv2 > WT_LEN || t->tableDiv1 > t->tableDiv2) return TRM_ERANGE;
     t->tnLength = t->tableDiv2 - t->tableDiv1;
     t->tnDelta = rint(WT_LEN * ((p->tnMax - p->tnMin) / 100.0));
     t->basicIncrement = (double)WT_LEN / (double)t->sampleRate;

@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 import cases
 
@@ -116,3 +117,22 @@ def test_shard_voices():
         assert b[0] == 0 and b[-1] == len(n) and all(x <= y for x, y in zip(b, b[1:]))
         cost = [int(n[lo:hi].sum()) for lo, hi in zip(b, b[1:])]
         assert max(cost) <= n.sum() / G + n.max()                              # within one voice of the even share
+
+
+def test_pulse_shape_beyond_the_table_is_refused():
+    """tp + tnMax above 100 % makes the reference write past its 512-entry wavetable (TRMWavetable.m:86-96, no check
+    there): the library (trm_derive, no device needed) and the oracle both refuse."""
+    import ctypes as C
+    import cases
+    import gnuspeech_amd as g
+    import oracle_lib as O
+    from gnuspeech_amd import shard
+    pd = cases.monet_default_params(44100.0)
+    pd.update(tp=60.0, tnMin=10.0, tnMax=45.0)
+    with pytest.raises(g.TrmError) as e:
+        shard.derive(g.TRMInputParameters.from_dict(pd))
+    assert e.value.code == 10
+    with pytest.raises(RuntimeError):
+        O.synthesize(O.InputParams.from_dict(pd), np.zeros((3, 16)))
+    pd.update(tp=40.0, tnMin=16.0, tnMax=32.0)                      # the Monet default shape is fine
+    shard.derive(g.TRMInputParameters.from_dict(pd))
