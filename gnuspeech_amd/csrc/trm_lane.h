@@ -235,6 +235,16 @@ TRM_HD void osc_read(const Const &C, double axd, double pos1, double pos2, SineL
 }
 
 // `j` = position in the control period (uniform), `sineTab` = 512-entry sine table lookup.
+// The oscillator's advance per half tube sample, f0/2 * 512/sampleRate table entries (TRMWavetable.m:178-181), rounded
+// to a multiple of 2^-30 entries.  Every phase the kernels form is a sum of such increments below 2^11, hence EXACT in
+// fp64: the four-lane kernel's prefix sums, the one-lane kernel's running sum and a stream cut anywhere arrive at the
+// same positions bit for bit, whatever the order of the additions.  (2^-31 entries of rounding per sample: a random
+// walk of 1e-6 entries over a million samples, far inside the tolerance.)
+TRM_HD double osc_increment(double f0, const Const &C)
+{
+    return rint_d(((f0 * 0.5) * C.basicIncrement) * 1073741824.0) * (1.0 / 1073741824.0);
+}
+
 template <class SineLookup>
 TRM_HD OscOut osc_sample(OscState &S, ExciteTrack &T, const Const &C, int j, SineLookup sineTab)
 {
@@ -246,7 +256,7 @@ TRM_HD OscOut osc_sample(OscState &S, ExciteTrack &T, const Const &C, int j, Sin
     O.ah1 = amplitude_f(fma_f((float)j, T.aspDelta, T.aspBase));
 
     // glottal source: 2x oversampled wavetable oscillator (TRMWavetable.m:117-195)
-    double inc = (T.f0 * 0.5) * C.basicIncrement;
+    double inc = osc_increment(T.f0, C);
     double pos1 = S.oscPos + inc;
     pos1 = pos1 > 511.0 ? pos1 - 512.0 : pos1;          // mod0(), :28-34
     double pos2 = pos1 + inc;

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 double axd = db >= 60.0 ? 1.0 : T.axGeo;      // amplitude() with its clamps (:294-296)
                 axd = db <= 0.0 ? 0.0 : axd;
                 const float ah1 = amplitude_f(fma_f((float)j, T.aspDelta, T.aspBase));
-                const double oinc = (T.f0 * 0.5) * C.basicIncrement;
+                const double oinc = osc_increment(T.f0, C);       // (a multiple of 2^-30: the sums below are exact)
                 // position after this lane's sample = P + the inclusive prefix sum of 2*inc over the slots
                 double pre = oinc + oinc;
                 pre += q_take<1, kPart1 | kPart2 | kPart3>(0.0, pre);

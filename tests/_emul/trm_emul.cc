@@ -137,7 +137,7 @@ extern "C" int trm_emul_synthesize_quad(const trm_input_params *p, const float *
             axd[s] = db <= 0.0 ? 0.0 : a;
             ax[s] = (float)axd[s];
             ah1[s] = amplitude_f(fma_f((float)jj[s], OT[s].aspDelta, OT[s].aspBase));
-            incs[s] = (OT[s].f0 * 0.5) * C.basicIncrement;
+            incs[s] = osc_increment(OT[s].f0, C);
             two[s] = incs[s] + incs[s];
         }
         double pre[kSlots];
