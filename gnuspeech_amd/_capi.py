@@ -60,7 +60,7 @@ EXPORTS = [
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_host_int16", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
-    "trm_shard_voices", "trm_multi_create", "trm_multi_destroy", "trm_multi_synthesize_host",
+    "trm_shard_voices", "trm_multi_create", "trm_multi_destroy", "trm_multi_synthesize_host", "trm_multi_synthesize_host_int16",
     "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
     "trm_stream_push", "trm_stream_finish",
     "trm_events_count_frames", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
@@ -129,6 +129,7 @@ def lib():
     L.trm_multi_create.argtypes = [C.POINTER(TrmInputParams), vp, C.c_size_t, C.POINTER(vp)]
     L.trm_multi_destroy.argtypes = [vp]
     L.trm_multi_synthesize_host.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
+    L.trm_multi_synthesize_host_int16.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]
     L.trm_batch_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]

@@ -246,3 +246,15 @@ class TRMMultiBatch(TRMBatch):
 
     def synthesize(self, voices, reuse_output=False):
         return self._synthesize_host(lib().trm_multi_synthesize_host, voices, reuse_output)
+
+    def synthesize_int16(self, voices, for_wav_data=False, reuse_output=False):
+        ch = 2 if self.inputParameters.channels == 2 else 1
+        return self._synthesize_host(lib().trm_multi_synthesize_host_int16, voices, reuse_output, dtype=np.int16, channels=ch,
+                                     extra=(int(bool(for_wav_data)),))
+
+    def _device_only(self, *a, **k):
+        raise NotImplementedError("TRMMultiBatch carries the host-buffer entries only (one trm_batch per device inside the library)")
+
+    prepare_device = synthesize_device = scale_to_int16_device = prepare_events_device = generate_frames_device = _device_only
+    noise_table = set_kernel = kernel_time_ms = _device_only
+    last_kernel = property(_device_only)

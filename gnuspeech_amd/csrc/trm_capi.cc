@@ -878,13 +878,13 @@ void trm_multi_destroy(trm_multi *m)
     delete m;
 }
 
-int trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
-                              const uint32_t *nframes, float *out, const uint64_t *out_offset,
-                              uint32_t *number_samples, float *max_sample)
+static int multi_synthesize_impl(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                                 const uint32_t *nframes, float *out, int16_t *out16, int for_wav_data, const uint64_t *out_offset,
+                                 uint32_t *number_samples, float *max_sample)
 {
     if (!m) return fail(TRM_EINVAL, "null handle");
     if (nvoices == 0) return TRM_OK;
-    if (!frames || !frame_offset || !nframes || !out || !out_offset || !number_samples || !max_sample)
+    if (!frames || !frame_offset || !nframes || (!out && !out16) || !out_offset || !number_samples || !max_sample)
         return fail(TRM_EINVAL, "null pointer");
     const size_t G = m->b.size();
     std::vector<size_t> bounds(G + 1);
@@ -924,8 +924,10 @@ int trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames,
         if (sh[g].hi == sh[g].lo) continue;
         th.emplace_back([&, g]() {
             Shard &s = sh[g];
-            s.rc = trm_batch_synthesize_host(m->b[g], s.hi - s.lo, frames + s.fLo * 16, s.foff.data(), nframes + s.lo,
-                                             out + s.oLo, s.ooff.data(), number_samples + s.lo, max_sample + s.lo);
+            const size_t ch = m->b[g]->params.channels == 2 ? 2 : 1;
+            s.rc = synthesize_host_impl(m->b[g], s.hi - s.lo, frames + s.fLo * 16, s.foff.data(), nframes + s.lo,
+                                        out ? out + s.oLo : nullptr, out16 ? out16 + s.oLo * ch : nullptr, for_wav_data, s.ooff.data(),
+                                        number_samples + s.lo, max_sample + s.lo);
             if (s.rc) s.err = trm_last_error();      // (the detail text is thread-local: carry it to the caller's thread)
         });
     }
@@ -933,6 +935,23 @@ int trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames,
     for (size_t g = 0; g < G; g++)
         if (sh[g].rc) return fail(sh[g].rc, "shard %zu (device %d): %s", g, m->b[g]->device, sh[g].err.c_str());
     return TRM_OK;
+}
+
+int trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                              const uint32_t *nframes, float *out, const uint64_t *out_offset,
+                              uint32_t *number_samples, float *max_sample)
+{
+    if (!out) return fail(TRM_EINVAL, "null pointer");
+    return multi_synthesize_impl(m, nvoices, frames, frame_offset, nframes, out, nullptr, 0, out_offset, number_samples, max_sample);
+}
+
+int trm_multi_synthesize_host_int16(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                                    const uint32_t *nframes, int16_t *out16, const uint64_t *out_offset,
+                                    uint32_t *number_samples, float *max_sample, int for_wav_data)
+{
+    if (!out16) return fail(TRM_EINVAL, "null pointer");
+    return multi_synthesize_impl(m, nvoices, frames, frame_offset, nframes, nullptr, out16, for_wav_data, out_offset, number_samples,
+                                 max_sample);
 }
 
 // ------------------------------------------------------------------ control-track generation

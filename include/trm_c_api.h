@@ -216,6 +216,11 @@ int  trm_multi_synthesize_host(trm_multi *m, size_t nvoices, const float *frames
                                const uint32_t *nframes, float *out, const uint64_t *out_offset,
                                uint32_t *number_samples, float *max_sample);
 
+/* trm_batch_synthesize_host_int16 over all devices. */
+int  trm_multi_synthesize_host_int16(trm_multi *m, size_t nvoices, const float *frames, const uint64_t *frame_offset,
+                                     const uint32_t *nframes, int16_t *out16, const uint64_t *out_offset,
+                                     uint32_t *number_samples, float *max_sample, int for_wav_data);
+
 /* Output normalisation on device, TRMTubeModel.m:370-389,420-484: int16 mono/stereo
  * from fp32 PCM with per-voice scale = 32767/max * amplitude(volume). */
 int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,

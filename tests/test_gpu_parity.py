@@ -445,6 +445,11 @@ def test_several_devices_from_one_process(g, form):
     assert np.array_equal(pcm3[0], pcm[0])
     pcm4, _, _ = m.synthesize(voices[:2])
     assert np.array_equal(pcm4[1], pcm[1])
+    p16, ns16, _ = m.synthesize_int16(voices)                                    # the int16 entry over the shards
+    q16, _, _ = g.TRMBatch(ip).synthesize_int16(voices)
+    assert np.array_equal(ns16, ns) and all(np.array_equal(a, b) for a, b in zip(p16, q16))
+    with pytest.raises(NotImplementedError):                                      # host-buffer entries only
+        m.prepare_device(voices)
     # voices laid out in REVERSE order in the output buffer: the shards' spans still do not interleave -> accepted;
     # alternating voices between two halves of the buffer: refused
     import ctypes as C
