@@ -91,6 +91,16 @@ def test_sound_file_writer_against_oracle_scaling(tmp_path):
             ref = O.scale_int16(O.InputParams.from_dict(pd), x.astype(np.float64), mx).astype(np.int32)
             diff = ((body - ref + 32768) % 65536) - 32768          # the file path's x2 stereo gain wraps like the reference's cast
             assert np.max(np.abs(diff)) == 0
+            # the container as independent parsers see it (python's sunau / aifc / wave)
+            import aifc
+            import sunau
+            import wave
+            rd = {0: sunau.open, 1: aifc.open, 2: wave.open}[fmt](path, "rb")
+            assert (rd.getnchannels(), rd.getsampwidth(), rd.getframerate(), rd.getnframes()) == (channels, 2, 22050, x.size)
+            payload = rd.readframes(x.size)
+            rd.close()
+            got = np.frombuffer(payload, dtype="<i2" if fmt == 2 else ">i2").astype(np.int32)
+            assert np.array_equal(got, body)
 
 
 def test_event_frame_count_needs_no_gpu():
