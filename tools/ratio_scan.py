@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, cases, gnuspeech_amd as g, oracle_lib as O
 rows = cases.load_gnuspeech_rows()
 voices = [rows[:200].copy(), rows[50:343].copy(), np.concatenate([rows, rows])[:600].copy()]
-for rate in (96000.0, 48000.0, 64000.0):
-  for L in np.arange(14.0, 30.5, 1.0):
+for rate in [float(x) for x in os.environ.get("SCAN_RATES", "96000,48000,64000").split(",")]:
+  for L in np.arange(float(os.environ.get("SCAN_L0", "14")), 30.5, float(os.environ.get("SCAN_DL", "1"))):
     pd = cases.monet_default_params(rate); pd["length"] = float(L)
     ip = g.TRMInputParameters.from_dict(pd); op = O.InputParams.from_dict(pd)
     ref = [O.synthesize(op, np.asarray(v, np.float32).astype(np.float64)) for v in voices]
