@@ -565,6 +565,39 @@ def test_launch_timing_is_bounded_and_complete(g):
     assert n == 0 and t == 0.0
 
 
+def test_concurrent_handles_from_threads(g):
+    """Handles are independent (include/trm_c_api.h): six threads, each creating fresh batch objects (the process-wide
+    noise sequence and the shared device tables under load, both converter branches) and synthesizing concurrently, get
+    the bits of a sequential run."""
+    import threading
+    rows5 = np.concatenate([cases.load_gnuspeech_rows()] * 5)
+    jobs = []
+    for i, rate in enumerate([44100.0, 16000.0, 22050.0, 8000.0, 48000.0, 11025.0]):
+        pd = cases.monet_default_params(rate)
+        pd["length"] = 14.0 + i
+        jobs.append((pd, [rows5[s:s + n].copy() for s, n in ((3 * i, 600 + 150 * i), (50, 80), (7, 300))]))
+
+    def work(pd, voices, out, k, reps):
+        res = []
+        for _ in range(reps):
+            b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+            res.append([p.copy() for p in b.synthesize(voices)[0]])
+        out[k] = res
+
+    seq, par = {}, {}
+    for k, (pd, v) in enumerate(jobs):
+        work(pd, v, seq, k, 1)
+    threads = [threading.Thread(target=work, args=(pd, v, par, k, 3)) for k, (pd, v) in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(len(jobs)):
+        assert len(par[k]) == 3
+        for res in par[k]:
+            assert all(np.array_equal(a, b) for a, b in zip(res, seq[k][0])), k
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
