@@ -65,7 +65,7 @@ EXPORTS = [
     "trm_stream_push", "trm_stream_finish",
     "trm_events_count_frames", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
     "trm_batch_set_kernel", "trm_batch_last_kernel",
-    "trm_batch_kernel_time_ms", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
+    "trm_batch_kernel_time_ms", "trm_batch_set_timing", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
 ]
 
 _lib = None
@@ -146,6 +146,7 @@ def lib():
     L.trm_batch_generate_frames_host.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(TrmIntonation), vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.trm_write_sound_file.argtypes = [C.POINTER(TrmInputParams), vp, C.c_size_t, C.c_float, C.c_char_p]
     L.trm_batch_set_kernel.argtypes = [vp, C.c_int]
+    L.trm_batch_set_timing.argtypes = [vp, C.c_int]
     L.trm_kernel_blocks_per_cu_form.argtypes = [C.c_int]
     L.trm_batch_last_kernel.argtypes = [vp]
     L.trm_batch_noise_table.argtypes = [vp, vp, C.c_size_t]

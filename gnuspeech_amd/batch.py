@@ -197,6 +197,10 @@ class TRMBatch:
         """'auto' | 'wide' (one voice per lane) | 'quad' (four lanes per voice); see include/trm_c_api.h."""
         check(lib().trm_batch_set_kernel(self._h, {"auto": 0, "wide": 1, "quad": 2}[kernel]))
 
+    def set_timing(self, on):
+        """Launch timing on / off; off, synthesize_device is pure stream work and can be captured into a HIP graph."""
+        check(lib().trm_batch_set_timing(self._h, int(bool(on))))
+
     @property
     def last_kernel(self):
         return {0: "auto", 1: "wide", 2: "quad"}[lib().trm_batch_last_kernel(self._h)]
@@ -256,5 +260,5 @@ class TRMMultiBatch(TRMBatch):
         raise NotImplementedError("TRMMultiBatch carries the host-buffer entries only (one trm_batch per device inside the library)")
 
     prepare_device = synthesize_device = scale_to_int16_device = prepare_events_device = generate_frames_device = _device_only
-    noise_table = set_kernel = kernel_time_ms = _device_only
+    noise_table = set_kernel = kernel_time_ms = set_timing = _device_only
     last_kernel = property(_device_only)

@@ -728,6 +728,13 @@ int trm_batch_set_kernel(trm_batch *b, int kernel)
 
 int trm_batch_last_kernel(const trm_batch *b) { return b ? b->lastKernel : TRM_KERNEL_AUTO; }
 
+int trm_batch_set_timing(trm_batch *b, int on)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    b->timing = on != 0;
+    return TRM_OK;
+}
+
 int trm_batch_kernel_time_ms(trm_batch *b, double *total_ms, uint32_t *launches)
 {
     if (!b || !total_ms || !launches) return fail(TRM_EINVAL, "null argument");

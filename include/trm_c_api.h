@@ -329,6 +329,10 @@ int  trm_batch_last_kernel(const trm_batch *batch);
 /* Average device time (ms) of the tube kernel launches since the last call, measured
  * with hipEvents on the launch stream; resets the accumulator.  Used by bench.py. */
 int  trm_batch_kernel_time_ms(trm_batch *batch, double *total_ms, uint32_t *launches);
+/* Launch timing on (default) / off.  Off, trm_batch_synthesize_device creates no events and queries none: the call is
+ * then only stream work (once the batch has synthesized an utterance at least as long, so that its tables are in place)
+ * and can be captured into a HIP graph (hipStreamBeginCapture / torch.cuda.graph) and replayed. */
+int  trm_batch_set_timing(trm_batch *batch, int on);
 
 /* Diagnostic: copies the first n entries of the device-resident low-passed noise sequence
  * (TRMUtility.m:71-85 + TRMFilters.m:81-86, generated on the GPU in fp64, stored fp32) to host. */

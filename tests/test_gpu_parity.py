@@ -598,6 +598,43 @@ def test_concurrent_handles_from_threads(g):
             assert all(np.array_equal(a, b) for a, b in zip(res, seq[k][0])), k
 
 
+def test_hip_graph_capture_and_replay(g, form):
+    """With launch timing off the device entry is pure stream work: captured once into a HIP graph (torch.cuda.graph) and
+    replayed, it reproduces the direct launch bit for bit, also after the input frames changed in place."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    fr = cases.config3_frames(40, nframes=26)
+    st = b.prepare_device(fr)
+    b.synthesize_device(st)                                   # direct launch: tables in place, reference result
+    torch.cuda.synchronize()
+    ref = st["out"].clone()
+    b.set_timing(False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        b.synthesize_device(st, side)                         # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        b.synthesize_device(st)
+    st["out"].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(st["out"], ref)
+    fr2 = cases.config3_frames(40, nframes=26, seed=7)        # new control tracks into the same device buffer
+    flat = torch.from_numpy(np.ascontiguousarray(fr2.reshape(-1, 16), dtype=np.float32)).to(st["frames"].device)
+    st["frames"].copy_(flat)
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = st["out"].clone()
+    b.synthesize_device(st)
+    torch.cuda.synchronize()
+    assert torch.equal(st["out"], replayed) and not torch.equal(replayed, ref)
+    t, n = b.kernel_time_ms()
+    b.set_timing(True)
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
