@@ -211,10 +211,10 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 j += kTB;
                 // 20 floats per sample: C8, alphaLR and bpAlpha are re-derived by the tube wave (1 op each)
                 float4 *dst = &sK[((buf * kTB + u) * kKQuads) * kWave + lane];
-                // (the junction coefficients travel as k * damping: tube_step's working form)
-                dst[0 * kWave] = make_float4(K.kd[0], K.kd[1], K.kd[2], K.kd[3]);
-                dst[1 * kWave] = make_float4(K.kd[4], K.kd[5], K.kd[6], K.onePlusK8);
-                dst[2 * kWave] = make_float4(K.alphaU, K.nkd1, K.bpBeta, K.bpGamma);
+                // (the junction coefficients travel as (1 + k) * damping: tube_step's working form)
+                dst[0 * kWave] = make_float4(K.td[0], K.td[1], K.td[2], K.td[3]);
+                dst[1 * kWave] = make_float4(K.td[4], K.td[5], K.td[6], K.onePlusK8);
+                dst[2 * kWave] = make_float4(K.alphaU, K.ntd1, K.bpBeta, K.bpGamma);
                 dst[3 * kWave] = make_float4(K.tap[0], K.tap[1], K.tap[2], K.tap[3]);
                 dst[4 * kWave] = make_float4(K.tap[4], K.tap[5], K.tap[6], K.tap[7]);
             }
@@ -242,10 +242,10 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             Excitation E;
             E.gin = x.x; E.sig = x.y; E.thr = x.z;
             Coefs K;
-            K.kd[0] = k0.x; K.kd[1] = k0.y; K.kd[2] = k0.z; K.kd[3] = k0.w;
-            K.kd[4] = k1.x; K.kd[5] = k1.y; K.kd[6] = k1.z; K.onePlusK8 = k1.w;
-            K.k[7] = K.onePlusK8 - 1.0f;                 // C8 (near -1 when the mouth closes: no cancellation here)
-            K.alphaU = k2.x; K.nkd1 = k2.y; K.bpBeta = k2.z; K.bpGamma = k2.w;
+            K.td[0] = k0.x; K.td[1] = k0.y; K.td[2] = k0.z; K.td[3] = k0.w;
+            K.td[4] = k1.x; K.td[5] = k1.y; K.td[6] = k1.z; K.onePlusK8 = k1.w;
+            K.k8 = K.onePlusK8 - 1.0f;                   // C8 (near -1 when the mouth closes: no cancellation here)
+            K.alphaU = k2.x; K.ntd1 = k2.y; K.bpBeta = k2.z; K.bpGamma = k2.w;
             K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);    // the three alphas sum to 2 (TRMTubeModel.m:733-736)
             K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;        // TRMFilters.m:16
             K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;

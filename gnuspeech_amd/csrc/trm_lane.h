@@ -58,6 +58,7 @@ TRM_HD float rint_f(float x) { return __builtin_rintf(x); }
 TRM_HD float rcp_f(float x) { return 1.0f / x; }
 TRM_HD float exp2_f(float x) { return exp2f(x); }
 TRM_HD float fma_f(float a, float b, float c) { return fmaf(a, b, c); }
+TRM_HD double fma_f(double a, double b, double c) { return fma(a, b, c); }   // (host studies with TRM_WG_T=double)
 TRM_HD double exp2_d(double x) { return exp2(x); }
 TRM_HD double rint_d(double x) { return rint(x); }
 TRM_HD float rint_f(float x) { return rintf(x); }
@@ -93,7 +94,8 @@ struct Const {
     float breath;               // breathiness/100                           (:210)
     float crossmixFactor;       // 1/amplitude(mixOffset)                    (:213)
     float nasalK[5];            // NC2..NC6, fixed                           (:692-707)
-    float nasalKd[4];           // NC2..NC5 times damping (the junctions' working form, tube_step)
+    float nasalTd[4];           // (1 + NC2..NC5) times damping, formed in double without cancellation: the junctions'
+                                // working form (tube_step)
     float onePlusNK6;           // 1 + NC6, formed in double                 (:849)
     float noseR1sq;             // noseRadius[1]^2, for NC1                  (:741)
     float apScaleSq;            // apScale^2, for C8                         (:724)
@@ -325,11 +327,11 @@ struct CoefTrack {
 };
 
 struct Coefs {
-    float k[8];                 // C1..C8                                   (:712-726)
-    float kd[7], nkd1;          // C1..C7, NC1 times damping: what the junctions multiply by (tube_step)
+    float k8;                   // C8                                       (:723-725)
+    float td[7], ntd1;          // (1 + C1..C7), (1 + NC1) times damping, formed without cancellation: what the
+                                // junctions multiply by (tube_step)         (:712-722, :738-743)
     float onePlusK8;            // 1 + C8 without cancellation              (:835)
     float alphaLR, alphaU;      // three-way junction                       (:730-736)
-    float nk1;                  // NC1                                      (:738-743)
     float tap[8];               // frication taps FC1..FC8                  (:748-773)
     float bpAlpha, bpBeta, bpGamma;   // frication band-pass                (TRMFilters.m:9-17)
     float pad_;
@@ -362,20 +364,18 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
     }
     float velum = fma_f(fj, T.delta[11], T.base[11]);
 
-    // scattering coefficients (:712-744)
-    for (int i = 0; i < 7; i++) {
-        K.k[i] = (r2[i] - r2[i + 1]) * rcp_f(r2[i] + r2[i + 1]);
-        K.kd[i] = K.k[i] * C.damping;
-    }
+    // scattering coefficients (:712-744) as transmission factors (1 + k) d = 2 a^2 d / (a^2 + b^2): no
+    // cancellation when a junction nearly closes (k -> -1), see tube_step
+    const float d2 = C.damping + C.damping;
+    for (int i = 0; i < 7; i++) K.td[i] = r2[i] * (d2 * rcp_f(r2[i] + r2[i + 1]));
     float rk8 = rcp_f(r2[7] + C.apScaleSq);
-    K.k[7] = (r2[7] - C.apScaleSq) * rk8;
+    K.k8 = (r2[7] - C.apScaleSq) * rk8;
     K.onePlusK8 = (r2[7] + r2[7]) * rk8;         // 1 + C8 without the cancellation of a nearly closed mouth
     float v2 = velum * velum;
     float jsum = 2.0f * rcp_f(r2[3] + r2[3] + v2);
     K.alphaLR = jsum * r2[3];
     K.alphaU = jsum * v2;
-    K.nk1 = (v2 - C.noseR1sq) * rcp_f(v2 + C.noseR1sq);
-    K.nkd1 = K.nk1 * C.damping;
+    K.ntd1 = v2 * (d2 * rcp_f(v2 + C.noseR1sq));
 }
 
 TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j)
@@ -479,24 +479,26 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
     float fric = 2.0f * fma_f(K.bpAlpha, E.sig - L.bpX2, fma_f(K.bpGamma, L.bpY1, -(K.bpBeta * L.bpY2)));
     L.bpX2 = L.bpX1; L.bpX1 = E.sig; L.bpY2 = L.bpY1; L.bpY1 = fric;
 
-    // Scattering junction between a (top wave from the left) and b (bottom wave from the right),
-    // (:783-816): T = (a + k (a - b)) d + inj, B = (b + k (a - b)) d, evaluated as
-    // T = d a + (k d)(a - b) + inj, B = d b + (k d)(a - b) with k d formed once per sample by the
-    // coefficient stage: 5 operations instead of 7, same value to rounding.
-    const float *kd = K.kd, *tap = K.tap, *k = K.k;
+    // Scattering junction between a (top wave from the left) and b (bottom wave from the right), (:783-816):
+    // T = (a + k (a - b)) d + inj, B = (b + k (a - b)) d.  With t = (1 + k) d formed by the coefficient stage WITHOUT
+    // cancellation this is T = d b + t (a - b) + inj, B = T - d (a - b): the same four operations as the literal form
+    // k d (a - b), but a nearly closed junction (k -> -1: a velum or a constriction that leaks into a quiet cavity)
+    // transmits t a with the relative accuracy of t instead of rounding it off against d a -- the literal form in
+    // fp32 put 2e-5 of error on a voice whose output is mostly such a leak (monet_vowel: closed mouth, velum 0.1).
+    const float *td = K.td, *tap = K.tap;
     const wg_t d = C.damping;
     const wg_t input = E.gin;
     const wg_t fr = fric;
+    auto junction = [&](float t, wg_t a, wg_t b, wg_t &T, wg_t &B) {
+        const wg_t df = a - b;
+        T = fma_f((wg_t)t, df, d * b);
+        B = fma_f(-d, df, T);
+    };
     nw.oT[0] = o.oB[0] * d + input;
-    {
-        wg_t m = kd[0] * (o.oT[0] - o.oB[1]);
-        nw.oT[1] = fma_f(d, o.oT[0], m);
-        nw.oB[0] = fma_f(d, o.oB[1], m);
-    }
+    junction(td[0], o.oT[0], o.oB[1], nw.oT[1], nw.oB[0]);
     for (int i = 1; i < 3; i++) {             // S2-S3, S3-S4 with taps FC1, FC2
-        wg_t m = kd[i] * (o.oT[i] - o.oB[i + 1]);
-        nw.oT[i + 1] = fma_f(d, o.oT[i], m) + tap[i - 1] * fr;
-        nw.oB[i] = fma_f(d, o.oB[i + 1], m);
+        junction(td[i], o.oT[i], o.oB[i + 1], nw.oT[i + 1], nw.oB[i]);
+        nw.oT[i + 1] += tap[i - 1] * fr;
     }
     {
         wg_t jp = K.alphaLR * o.oT[3] + (K.alphaLR * o.oB[4] + K.alphaU * o.nB[0]);
@@ -504,21 +506,17 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
         nw.oT[4] = (jp - o.oB[4]) * d + tap[2] * fr;
         nw.nT[0] = (jp - o.nB[0]) * d;
     }
-    {
-        wg_t m = kd[3] * (o.oT[4] - o.oB[5]);
-        nw.oT[5] = fma_f(d, o.oT[4], m) + tap[3] * fr;
-        nw.oB[4] = fma_f(d, o.oB[5], m);
-    }
-    nw.oT[6] = o.oT[5] * d + tap[4] * fr;
-    nw.oB[5] = o.oB[6] * d;
+    junction(td[3], o.oT[4], o.oB[5], nw.oT[5], nw.oB[4]);
+    nw.oT[5] += tap[3] * fr;
+    junction(C.damping, o.oT[5], o.oB[6], nw.oT[6], nw.oB[5]);      // the junction-less S6|S7 boundary: k = 0
+    nw.oT[6] += tap[4] * fr;
     for (int i = 6; i < 9; i++) {             // S7-S8, S8-S9, S9-S10 with taps FC6..FC8
-        wg_t m = kd[i - 2] * (o.oT[i] - o.oB[i + 1]);
-        nw.oT[i + 1] = fma_f(d, o.oT[i], m) + tap[i - 1] * fr;
-        nw.oB[i] = fma_f(d, o.oB[i + 1], m);
+        junction(td[i - 2], o.oT[i], o.oB[i + 1], nw.oT[i + 1], nw.oB[i]);
+        nw.oT[i + 1] += tap[i - 1] * fr;
     }
     wg_t out;
     {   // mouth: reflection y = a10*x - b11*y1, radiation y = a20*x + a21*x1 - b21*y1 (TRMFilters.m:47-60)
-        wg_t refl = C.mA10 * (k[7] * o.oT[9]) + C.mCoeff * L.mReflY;
+        wg_t refl = C.mA10 * (K.k8 * o.oT[9]) + C.mCoeff * L.mReflY;
         L.mReflY = refl;
         nw.oB[9] = d * refl;
         wg_t rin = K.onePlusK8 * o.oT[9];
@@ -527,12 +525,8 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
         out = rad;
     }
     {
-        float kk[5] = {K.nkd1, C.nasalKd[0], C.nasalKd[1], C.nasalKd[2], C.nasalKd[3]};
-        for (int i = 0; i < 5; i++) {
-            wg_t m = kk[i] * (o.nT[i] - o.nB[i + 1]);
-            nw.nT[i + 1] = fma_f(d, o.nT[i], m);
-            nw.nB[i] = fma_f(d, o.nB[i + 1], m);
-        }
+        float tt[5] = {K.ntd1, C.nasalTd[0], C.nasalTd[1], C.nasalTd[2], C.nasalTd[3]};
+        for (int i = 0; i < 5; i++) junction(tt[i], o.nT[i], o.nB[i + 1], nw.nT[i + 1], nw.nB[i]);
         wg_t refl = C.nA10 * (C.nasalK[4] * o.nT[5]) + C.nCoeff * L.nReflY;
         L.nReflY = refl;
         nw.nB[5] = d * refl;

@@ -79,15 +79,15 @@ __device__ __forceinline__ double q_take(double old, double src)
 // (T0, T2) pair, the b-inputs of rounds (0, 2) are the (B1, B3) pair, and in part 2 the two ends read the
 // (T1, T3) pair and write the b-inputs of rounds (1, 3).
 struct PartRecord {
-    float kk[4];        // scattering coefficients x damping of rounds 0, 2, 1, 3 (part 1's idle round 3: alphaU)
+    float kk[4];        // junction transmission factors (1 + k) d of rounds 0, 2, 1, 3 (tube_step's working form; part 1's
+                        // idle round 3: alphaU; other idle rounds 0; the junction-less S6|S7 boundary: d)
     float tp[4];        // frication taps of rounds 0, 2, 1, 3          (part 1's idle round 3: FC3)
 };
 
 TRM_HD void pack_part_kk(const Coefs &K, const Const &C, PartRecord R[4])      // needs coef_sample_area's fields
 {
-    // (junction coefficients as k * damping: tube_step's working form)
-    const float kk[4][4] = {{K.kd[0], K.kd[2], K.kd[1], 0.0f}, {K.kd[3], K.kd[4], 0.0f, K.alphaU},
-                            {K.kd[5], 0.0f, K.kd[6], C.nasalKd[3]}, {K.nkd1, C.nasalKd[1], C.nasalKd[0], C.nasalKd[2]}};
+    const float kk[4][4] = {{K.td[0], K.td[2], K.td[1], 0.0f}, {K.td[3], K.td[4], C.damping, K.alphaU},
+                            {K.td[5], 0.0f, K.td[6], C.nasalTd[3]}, {K.ntd1, C.nasalTd[1], C.nasalTd[0], C.nasalTd[2]}};
     for (int p = 0; p < 4; p++)
         for (int i = 0; i < 4; i++) R[p].kk[i] = kk[p][i];
 }
@@ -118,7 +118,7 @@ TRM_HD void pack_shared_bp(const Coefs &K, SharedRecord &R)                     
 }
 TRM_HD void pack_shared_end(const Coefs &K, const Const &C, SharedRecord &R)    // coef_sample_area's fields
 {
-    R.endK[0] = K.onePlusK8 - 1.0f;     // C8 (near -1 when the mouth closes: no cancellation here)
+    R.endK[0] = K.k8;
     R.endK[1] = C.nasalK[4];
     R.endOnePlus[0] = K.onePlusK8;
     R.endOnePlus[1] = C.onePlusNK6;
@@ -217,13 +217,15 @@ TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F fr, F ty, type
 
     // ---- generic junctions (:783-816, :838-846), two rounds per operation
     const P dd = pk_make(d, d), ff = pk_make(fr, fr);
-    // T = d a + (k d)(a - b) + tap fr, B = d b + (k d)(a - b): kA / kB carry k d (tube_step)
-    const P mA = kA * (aA - bA), mB = kB * (aB - bB);
+    // T = d b + t (a - b) + tap fr, B = T - d (a - b): kA / kB carry t = (1 + k) d (tube_step)
+    const P dfA = aA - bA, dfB = aB - bB;
     const P inA = tA * ff, inB = tB * ff;
-    S.TA = pk_fma(dd, aA, mA) + inA;
-    S.TB = pk_fma(dd, aB, mB) + inB;
-    S.BA = pk_fma(dd, bA, mA);
-    S.BB = pk_fma(dd, bB, mB);
+    const P ndd = pk_make(-d, -d);
+    const P TA = pk_fma(kA, dfA, dd * bA), TB = pk_fma(kB, dfB, dd * bB);
+    S.BA = pk_fma(ndd, dfA, TA);
+    S.BB = pk_fma(ndd, dfB, TB);
+    S.TA = TA + inA;
+    S.TB = TB + inB;
     // ---- glottis end (:781)
     S.A0 = x2 * d + gin;
     // ---- three-way junction (:801-806); the three alphas sum to 2 (:733-736)

@@ -36,6 +36,22 @@
 
 namespace trm {
 
+// The two LDS words through which the mix and convert waves hand coefficient rows to each other outside the step
+// barrier.  Publishing = LDS-only release fence (every lane: the rows were stored by all of them), then the flag;
+// consuming = the flag, then an LDS-only acquire fence.  "local": the fences order LDS traffic only -- a full
+// workgroup-scope release would also drain the convert wave's PCM stores (vmcnt), which nobody here reads.
+__device__ __forceinline__ void lds_flag_publish(uint32_t *flag, uint32_t value, bool writer)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (writer) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_flag_consume(uint32_t *flag)
+{
+    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    return v;
+}
+
 constexpr int kQV = 16;              // voices per workgroup
 constexpr int kQB = kSlots;          // tube samples per block = time slots per voice
 constexpr int kSub = 2;              // blocks per pipeline step: the feed-forward waves run two INDEPENDENT blocks per
@@ -319,14 +335,14 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 float4 *dst = reinterpret_cast<float4 *>(&sRows[((rowBlk - 1) % kRowBufs) * (kCvtCols * kRowPitch) + (lane >> 1) * kRowPitch + (lane & 1) * 16]);
                 for (int q = 0; q < 4; q++) dst[q] = rq[q];
                 rowsInFlight = false;
-                if (lane == 0) sRowSync[1] = rowBlk;            // blocks 0 .. rowBlk-1 are in LDS after this step's barrier
+                lds_flag_publish(&sRowSync[1], rowBlk, lane == 0);     // blocks 0 .. rowBlk-1 are in LDS
             };
             if (rowsInFlight) rows_to_lds();
             // never more than kRowBufs blocks past the first one the convert wave still has to copy (looked up only
             // when a block is due: about once per block).  Up to two blocks per step (rate ratios above 4).
             for (int r = 0; r < 2; r++) {
                 if (TRM_ABL_CVT != 4 && rowBlk < cvtBlocks && src_position(kBase + rowBlk * kCvtCols, inc) - nBase <= step * kStepN + 4u &&
-                    rowBlk < __builtin_amdgcn_readfirstlane(sRowSync[0]) + kRowBufs) {
+                    rowBlk < lds_flag_consume(&sRowSync[0]) + kRowBufs) {
                     if (rowsInFlight) rows_to_lds();            // (a second block in the same step: its predecessor's loads are waited for here)
                     const uint32_t k = kBase + rowBlk * kCvtCols + ((uint32_t)lane >> 1);
                     const uint32_t off = (src_position(k, inc) - nBase + (kQLead - (kSrcWindow - 1))) & 3u;
@@ -662,10 +678,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             if (credit > creditCap) credit = creditCap;     // a ready block is spread over the next steps, not done in a burst
             // (the two sync words are touched once per block: when a block has to begin)
             auto try_begin = [&]() {
-                if (TRM_ABL_CVT == 4 || blk < __builtin_amdgcn_readfirstlane(sRowSync[1])) {
+                if (TRM_ABL_CVT == 4 || blk < lds_flag_consume(&sRowSync[1])) {
                     begin_block();
                     needBegin = false;
-                    if (lane == 0) sRowSync[0] = blk + 1;       // this block's rows are in registers now
+                    lds_flag_publish(&sRowSync[0], blk + 1, lane == 0);    // this block's rows are in registers now
                 }
             };
             if (needBegin) try_begin();
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         }
         STAMP_STORE(role)
         {   // after the last barrier: what is staged is final; a block beyond it fetches its row itself
-            const uint32_t staged = __builtin_amdgcn_readfirstlane(sRowSync[1]);
+            const uint32_t staged = lds_flag_consume(&sRowSync[1]);
             while (blk < nBlocks) {
                 if (needBegin) {
                     if (blk < staged) begin_block();

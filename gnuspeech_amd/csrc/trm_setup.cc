@@ -230,7 +230,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     for (int i = 1; i < 5; i++) {                                        // :695-699
         double a2 = p.noseRadius[i] * p.noseRadius[i], b2 = p.noseRadius[i + 1] * p.noseRadius[i + 1];
         c.nasalK[i - 1] = (float)((a2 - b2) / (a2 + b2));
-        c.nasalKd[i - 1] = c.nasalK[i - 1] * c.damping;
+        c.nasalTd[i - 1] = (float)((a2 + a2) / (a2 + b2) * (1.0 - p.lossFactor / 100.0));   // (1 + k) d without cancellation
     }
     {
         double a2 = p.noseRadius[5] * p.noseRadius[5], b2 = p.apScale * p.apScale;   // :703-705

@@ -681,6 +681,26 @@ int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_
     return rc;
 }
 
+/* bench.py's cpu_baseline leg: `count` voices of `nframes` frames each (frames = [voices][nframes][16] doubles),
+ * starting at voice `first` and wrapping at `nvoices`, one after the other on the calling thread; returns the output
+ * samples produced.  The library keeps no global state: any number of threads may run this at once. */
+int trm_oracle_run_voices(const trm_input_params *p, const double *frames, size_t nframes, size_t nvoices,
+                          size_t first, size_t count, uint64_t *samples_out)
+{
+    uint64_t total = 0;
+    if (!p || !frames || nvoices == 0) return TRM_EINVAL;
+    for (size_t i = 0; i < count; i++) {
+        trm_oracle_result r;
+        const size_t v = (first + i) % nvoices;
+        int rc = trm_oracle_synthesize(p, frames + v * nframes * 16, nframes, 0, &r);
+        if (rc) return rc;
+        total += (uint64_t)r.numberSamples;
+        trm_oracle_result_free(&r);
+    }
+    if (samples_out) *samples_out = total;
+    return TRM_OK;
+}
+
 void trm_oracle_result_free(trm_oracle_result *r)
 {
     if (!r) return;

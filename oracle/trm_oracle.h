@@ -37,6 +37,9 @@ typedef struct trm_oracle_result {
 int  trm_oracle_synthesize(const trm_input_params *params, const double *frames, size_t nframes,
                            int keep_tube_samples, trm_oracle_result *out);
 void trm_oracle_result_free(trm_oracle_result *r);
+/* `count` voices in a row on the calling thread (bench.py's cpu_baseline: one call per thread, no Python in the loop) */
+int  trm_oracle_run_voices(const trm_input_params *params, const double *frames, size_t nframes, size_t nvoices,
+                           size_t first, size_t count, uint64_t *samples_out);
 
 /* derived constants only (TRMTubeModel.m:196-203, TRMSampleRateConverter.m:69-104) */
 int  trm_oracle_derive(const trm_input_params *params, trm_derived *out);

@@ -208,12 +208,12 @@ extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, uns
     for (int it = 0; it < iters; it++) {
         if (it % 200 == 0) { tube_reset(TS); quad_reset(QS); }   // random coefficients are not a passive tube: keep it finite
         Coefs K;
-        for (int i = 0; i < 7; i++) { K.k[i] = rnd() * 0.9f; K.kd[i] = K.k[i] * C.damping; }
+        for (int i = 0; i < 7; i++) K.td[i] = (1.0f + rnd() * 0.9f) * C.damping;
         K.onePlusK8 = 1.0f + rnd() * 0.9f;
-        K.k[7] = K.onePlusK8 - 1.0f;
+        K.k8 = K.onePlusK8 - 1.0f;
         K.alphaU = rnd() * 0.5f + 0.5f;
         K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);
-        K.nk1 = rnd() * 0.9f; K.nkd1 = K.nk1 * C.damping;
+        K.ntd1 = (1.0f + rnd() * 0.9f) * C.damping;
         for (int i = 0; i < 8; i++) K.tap[i] = rnd() * 0.1f;
         K.bpBeta = 0.2f + rnd() * 0.2f; K.bpGamma = rnd() * 0.3f; K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
         Excitation E; E.gin = rnd(); E.sig = rnd(); E.thr = rnd();

@@ -79,6 +79,9 @@ def lib():
                                             C.c_int, C.POINTER(_Result)]
         L.trm_oracle_synthesize.restype = C.c_int
         L.trm_oracle_result_free.argtypes = [C.POINTER(_Result)]
+        L.trm_oracle_run_voices.argtypes = [C.POINTER(InputParams), C.POINTER(C.c_double), C.c_size_t, C.c_size_t,
+                                            C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.trm_oracle_run_voices.restype = C.c_int
         L.trm_oracle_derive.argtypes = [C.POINTER(InputParams), C.POINTER(Derived)]
         L.trm_oracle_derive.restype = C.c_int
         L.trm_oracle_fir_taps.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int]

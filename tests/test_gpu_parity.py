@@ -13,11 +13,7 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-RMS_TOL = 1e-5
-# Closed mouth (r8 = 0.01) + nearly closed velum + full voicing: a near-lossless cavity in which the
-# fp32 waveguide's rounding noise is amplified by the resonance (measured 2.1e-5 with the identical
-# arithmetic on the host, 4e-6 with an fp64 waveguide).  Speech-like tracks sit at ~1e-6.
-STRESS_TOL = {"monet_vowel_44k": 4e-5, "monet_vowel_22k": 4e-5}
+RMS_TOL = 1e-5      # ONE tolerance for every fixture, both kernel forms and the randomized voices (north_star)
 ALL_CASES = list(golden_io.CASE_NAMES)      # incl. short_tube_downsample: the converter's down-sampling branch
 
 
@@ -59,7 +55,7 @@ def test_tube_model_matches_reference_fixture(g, form, name):
     mx = gold["maximumSampleValue"]
     out = tube.samples()
     assert np.all(np.isfinite(out))
-    tol = STRESS_TOL.get(name, RMS_TOL)
+    tol = RMS_TOL
     err = nrms(out, gold["samples_f32"].astype(np.float64), mx)
     assert err <= tol, "normalised RMS %.3e > %.1e" % (err, tol)
     assert abs(tube.maximumSampleValue - mx) / mx < 2e-4
@@ -237,7 +233,7 @@ def test_random_voices_and_tracks(g, form, seed):
         fr = np.stack([track(-10, 6), track(0, 60), track(0, 20), track(0, 40), track(0, 7), track(500, 5000), track(200, 2500)]
                       + [track(0.05, 2.5) for _ in range(8)] + [track(0.0, 1.2)], axis=1)
         voices.append(fr)
-    _batch_vs_oracle(g, pd, voices, tol=2e-5)
+    _batch_vs_oracle(g, pd, voices)
 
 
 def test_tract_defaults_and_sine(g, form):

@@ -135,3 +135,24 @@ def test_random_parameters_and_chunkings(g, seed):
     assert got.shape[1] == int(ns[0])
     for v in range(V):
         assert nrms(got[v], pcm[v], mx[v]) <= 4e-6, "voice %d" % v
+
+
+@pytest.mark.parametrize("rate,seed", [(44100.0, 0), (22050.0, 1), (16000.0, 2), (8000.0, 3), (44100.0, 4), (11025.0, 5)])
+def test_stream_matches_oracle(g, rate, seed):
+    """The streamed utterance against the ORACLE (not against another HIP path): random cuts, both converter branches,
+    exact sample counts, normalised RMS <= 1e-5 -- the same bar as the one-shot path (tests/test_gpu_parity.py)."""
+    import oracle_lib as O
+    rng = np.random.default_rng(900 + seed)
+    pd = cases.monet_default_params(rate)
+    V, n = 5, 40
+    fr = cases.config3_frames(V, nframes=n, seed=20250118 + seed).astype(np.float32)
+    cuts = np.sort(rng.choice(np.arange(1, n), size=int(rng.integers(1, 7)), replace=False))
+    chunks = [int(c) for c in np.diff(np.concatenate([[0], cuts, [n]]))]
+    got, got_max, _ = stream_all(g, pd, fr, chunks)
+    op = O.InputParams.from_dict(pd)
+    for v in range(V):
+        o = O.synthesize(op, fr[v].astype(np.float64))
+        assert got.shape[1] == o["numberSamples"], (chunks, got.shape[1], o["numberSamples"])
+        e = nrms(got[v], o["samples"], o["maximumSampleValue"])
+        assert e <= 1e-5, "voice %d: normalised RMS %.3e, chunks %s" % (v, e, chunks)
+        assert abs(float(got_max[v]) - o["maximumSampleValue"]) / o["maximumSampleValue"] < 2e-4

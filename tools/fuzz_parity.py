@@ -60,6 +60,6 @@ for seed in range(first, last):
             if o["numberSamples"] == 0 or o["maximumSampleValue"] == 0: continue
             e = (pcm[v].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
             r = float(np.sqrt(np.mean(e * e)))
-            if not r <= 2e-5:
+            if not r <= 1e-5:
                 print("seed %d %s voice %d (%d frames, length %.1f, rate %.0f/%.0f): rms %.3e" % (seed, form, v, len(voices[v]), pd["length"], pd["outputRate"], pd["controlRate"], r)); bad += 1
 print("done: seeds %d..%d, %d findings" % (first, last, bad))
