@@ -37,6 +37,25 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut to the cgroup's CPU quota where there is one
+    (a GPU box hands each job a share of its host, e.g. 16 of 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(pd, frames, wall_s=3.0):
     """The oracle (CPU restatement of Frameworks/Tube, double precision: oracle/trm_oracle.c) timed on this host: one
     voice per task, in-process threads on all host cores (ctypes drops the GIL; the C library keeps no global state;
@@ -47,7 +66,13 @@ def cpu_baseline(pd, frames, wall_s=3.0):
     import numpy as np
     import oracle_lib as O
     L = O.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    try:        # keep the per-voice buffers (350 KB) on the heap: mmap / munmap per voice serialises the threads in the kernel
+        libc = C.CDLL(None)
+        libc.mallopt(-3, 1 << 30)       # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 1 << 30)       # M_TRIM_THRESHOLD
+    except (OSError, AttributeError):
+        pass
     fr = np.ascontiguousarray(np.asarray(frames, dtype=np.float32).astype(np.float64))     # what the GPU path is handed
     nv, nf = fr.shape[0], fr.shape[1]
     op = O.InputParams.from_dict(pd)
@@ -80,8 +105,9 @@ def cpu_baseline(pd, frames, wall_s=3.0):
         t.join()
     return {"value": float(sum(res)) / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "per_core": float(sum(res)) / dt / cores,
+            "host_hardware_threads": os.cpu_count(),
             "sample": "%d voice runs (the workload's %d voices cyclically, %d output samples each) = %.0f s of CPU work in "
-                      "%.2f s on %d threads, oracle/trm_oracle.c (double), one voice per task"
+                      "%.2f s on %d threads (the cores this job may use), oracle/trm_oracle.c (double), one voice per task"
                       % (cores * per_thread, nv, per_voice_samples, dt * cores, dt, cores)}
 
 

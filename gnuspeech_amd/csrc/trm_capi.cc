@@ -99,6 +99,11 @@ struct trm_batch {
     int kernel = TRM_KERNEL_AUTO;        // trm_batch_set_kernel
     uint32_t wideThreshold = 4097;       // voices from which the one-voice-per-lane kernel is the faster form (set at create)
     int lastKernel = TRM_KERNEL_AUTO;    // what the last launch ran
+    int cus = 0;                         // compute units of the device (set at create)
+    int envKernel = TRM_KERNEL_AUTO;     // TRM_TUBE_KERNEL, read once at create (steers launches left on AUTO; tests)
+    bool envDownGeneric = false;         // TRM_DOWNSAMPLE_GENERIC, read once at create (tests: the generic down-sampling kernel)
+    size_t tubeOffVoices = 0;            // dTubeOff holds pitch * v for v < tubeOffVoices ...
+    uint64_t tubeOffPitch = 0;           // ... at this row pitch (down-sampling batches: rebuilt only when either changes)
 };
 
 struct trm_tube {
@@ -142,7 +147,7 @@ const char *trm_build_info(void) { return "libtrm_hip gfx950 (one tube per lane,
 int trm_kernel_blocks_per_cu(void) { return trm::tube_kernel_blocks_per_cu(); }
 int trm_kernel_blocks_per_cu_form(int kernel)
 {
-    return kernel == TRM_KERNEL_QUAD ? trm::tube_quad_kernel_blocks_per_cu() : trm::tube_kernel_blocks_per_cu();
+    return kernel == TRM_KERNEL_QUAD ? trm::tube_quad_kernel_blocks_per_cu(1) : trm::tube_kernel_blocks_per_cu();
 }
 
 void trm_free(void *p) { free(p); }
@@ -183,6 +188,10 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     // four SIMDs busy, so more voices run in rounds (measured on 256 CUs: 4096 voices 3.1 ms, 8192 6.2 ms, 12288
     // 9.0 ms) while the one-voice-per-lane form takes 7.1 ms for anything up to 16384 (profiles/sweep_forms_r01.txt).
     b->wideThreshold = 2u * 16u * (uint32_t)prop.multiProcessorCount + 1u;
+    b->cus = prop.multiProcessorCount;
+    if (const char *e = getenv("TRM_QUAD_CUS")) b->cus = atoi(e);     // (experiments: 0 = always two blocks per step, 1 = always one)
+    if (const char *e = getenv("TRM_TUBE_KERNEL")) b->envKernel = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : TRM_KERNEL_AUTO;
+    b->envDownGeneric = getenv("TRM_DOWNSAMPLE_GENERIC") != nullptr;
     hipError_t e;
 #define B_TRY(expr)                                                              \
     if ((e = (expr)) != hipSuccess) {                                            \
@@ -307,9 +316,11 @@ static bool quad_ratio_too_high(const trm::Const &c) { return c.upsample && c.ti
 static int fold_events(trm_batch *b, bool wait)
 {
     size_t done = 0;
+    hipError_t bad = hipSuccess;
     for (auto &ev : b->events) {
-        if (wait) HIP_TRY(hipEventSynchronize(ev.second));
-        else if (hipEventQuery(ev.second) != hipSuccess) break;         // (in stream order: the later ones are not finished either)
+        if (wait) {
+            if ((bad = hipEventSynchronize(ev.second)) != hipSuccess) break;       // (this pair stays in the list, untouched)
+        } else if (hipEventQuery(ev.second) != hipSuccess) break;       // (in stream order: the later ones are not finished either)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
             b->timedMs += ms;
@@ -319,7 +330,8 @@ static int fold_events(trm_batch *b, bool wait)
         (void)hipEventDestroy(ev.second);
         done++;
     }
-    b->events.erase(b->events.begin(), b->events.begin() + done);
+    b->events.erase(b->events.begin(), b->events.begin() + done);     // the pairs destroyed above leave the list, error or not
+    if (bad != hipSuccess) return fail(TRM_EHIP, "hipEventSynchronize: %s", hipGetErrorString(bad));
     return TRM_OK;
 }
 
@@ -413,11 +425,17 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         // tube rate above the output rate: tube-rate samples go through HBM to the down-sampling kernel;
         // voice v gets a fixed-pitch row of (max_nframes-1)*controlPeriod + 2*pad floats
         const uint64_t pitch = (ntubeMax + 2ull * (uint64_t)b->d.padSize + 3ull) & ~3ull;      // rows 16-byte aligned
-        if ((rc = b->dTube.reserve(pitch * nvoices + 1)) || (rc = b->dTubeOff.reserve(nvoices))) return rc;
-        std::vector<uint64_t> offs(nvoices);
-        for (size_t i = 0; i < nvoices; i++) offs[i] = pitch * i;
-        HIP_TRY(hipMemcpyAsync(b->dTubeOff.p, offs.data(), nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));      // offs is a stack temporary
+        if ((rc = b->dTube.reserve(pitch * nvoices + 1))) return rc;
+        if (b->tubeOffPitch != pitch || b->tubeOffVoices < nvoices) {
+            // the row offsets pitch * v: uploaded when the batch shape changes, not per launch -- the entry stays pure
+            // stream work (asynchronous, capturable) for every call that repeats a shape
+            if ((rc = b->dTubeOff.reserve(nvoices))) return rc;
+            std::vector<uint64_t> offs(nvoices);
+            for (size_t i = 0; i < nvoices; i++) offs[i] = pitch * i;
+            HIP_TRY(hipMemcpy(b->dTubeOff.p, offs.data(), nvoices * sizeof(uint64_t), hipMemcpyHostToDevice));
+            b->tubeOffPitch = pitch;
+            b->tubeOffVoices = nvoices;
+        }
         a.tube_out = b->dTube.p;
         a.tube_offset = b->dTubeOff.p;
     }
@@ -446,9 +464,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // every CU; below that, four lanes per voice (16 voices per workgroup), which advances four tube
     // samples per pass of the instruction streams and spreads a small batch over four times the CUs.
     int which = b->kernel;
-    if (which == TRM_KERNEL_AUTO) {
-        if (const char *e = getenv("TRM_TUBE_KERNEL")) which = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : which;
-    }
+    if (which == TRM_KERNEL_AUTO) which = b->envKernel;
     if (which == TRM_KERNEL_AUTO) which = nvoices >= (size_t)b->wideThreshold ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD;
     // The four-lane form's converter is fed one block of coefficient rows per step by design (two at a push): four
     // outputs per tube sample.  It measured clean to 5.3 and wrong from 5.6 on (the ring laps the converter;
@@ -457,7 +473,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     if (which == TRM_KERNEL_QUAD && quad_ratio_too_high(b->c)) which = TRM_KERNEL_WIDE;
     b->lastKernel = which;
     if (which == TRM_KERNEL_QUAD)
-        HIP_TRY(trm::launch_tube_quad(b->c, a, stream));
+        HIP_TRY(trm::launch_tube_quad(b->c, a, stream, b->cus));
     else
         HIP_TRY(trm::launch_tube(b->c, a, stream));
     if (!b->c.upsample) {
@@ -472,7 +488,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         d.fine = b->dFine;
         d.nvoices = (uint32_t)nvoices;
         d.max_nframes = max_nframes;
-        d.rows = getenv("TRM_DOWNSAMPLE_GENERIC") ? nullptr : b->dDownRows;     // (tests: the generic kernel must agree bit for bit)
+        d.rows = b->envDownGeneric ? nullptr : b->dDownRows;     // (tests: the generic kernel must agree bit for bit)
         d.lmax = b->downL; d.rmax = b->downR; d.pitch = b->downPitch;
         d.stream = 0; d.n_origin = d.n_hi = 0; d.k_base = d.k_end = 0;
         HIP_TRY(trm::launch_downsample(b->c, d, stream));
@@ -650,7 +666,7 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         a.stream_n_base = (uint32_t)s->nBase;
         a.stream_k_base = (uint32_t)s->kBase;
         a.stream_k_end = (uint32_t)kEnd;
-        HIP_TRY(trm::launch_tube_quad(b->c, a, st));
+        HIP_TRY(trm::launch_tube_quad(b->c, a, st, b->cus));
         s->first = false;
         if (down) {
             if (count > 0) {
@@ -780,15 +796,23 @@ static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frame
     if (!frames || !frame_offset || !nframes || (!out && !out16) || !out_offset || !number_samples || !max_sample)
         return fail(TRM_EINVAL, "null pointer");
     HIP_TRY(hipSetDevice(b->device));
-    uint64_t frameRows = 0, outEnd = 0;
+    uint64_t frameRows = 0, outEnd = 0, outBegin = ~0ull, outSum = 0;
     uint32_t maxFrames = 0;
     for (size_t v = 0; v < nvoices; v++) {
         uint64_t fe = frame_offset[v] + nframes[v];
         if (fe > frameRows) frameRows = fe;
-        uint64_t oe = out_offset[v] + trm_batch_samples_for_frames(b, nframes[v]);
+        const uint64_t ns = trm_batch_samples_for_frames(b, nframes[v]);
+        uint64_t oe = out_offset[v] + ns;
         if (oe > outEnd) outEnd = oe;
+        if (ns > 0 && out_offset[v] < outBegin) outBegin = out_offset[v];
+        outSum += ns;
         if (nframes[v] > maxFrames) maxFrames = nframes[v];
     }
+    if (outBegin > outEnd) outBegin = outEnd;
+    // The header promises writes at out + out_offset[v] only.  Dense spans (the usual case: the voices tile
+    // [outBegin, outEnd) exactly) come back in one copy; a span with gaps is copied voice by voice, so that what
+    // lies between the voices in the caller's buffer is left alone.
+    const bool dense = outSum == outEnd - outBegin;
     if (frameRows == 0) frameRows = 1;
     const size_t ch = b->params.channels == 2 ? 2 : 1;
     int rc;
@@ -809,9 +833,17 @@ static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frame
         rc = trm_batch_scale_to_int16_device(b, nvoices, b->dOut.p, b->dOutOff.p, b->dNSamples.p, b->dMax.p, b->dOut16.p,
                                              for_wav_data, s);
         if (rc) return rc;
-        if (outEnd) HIP_TRY(hipMemcpyAsync(out16, b->dOut16.p, outEnd * ch * sizeof(int16_t), hipMemcpyDeviceToHost, s));
-    } else if (outEnd) {
-        HIP_TRY(hipMemcpyAsync(out, b->dOut.p, outEnd * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (dense && outEnd > outBegin)
+            HIP_TRY(hipMemcpyAsync(out16 + outBegin * ch, b->dOut16.p + outBegin * ch, (outEnd - outBegin) * ch * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+        for (size_t v = 0; !dense && v < nvoices; v++)
+            if (const uint64_t ns = trm_batch_samples_for_frames(b, nframes[v]))
+                HIP_TRY(hipMemcpyAsync(out16 + out_offset[v] * ch, b->dOut16.p + out_offset[v] * ch, ns * ch * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    } else {
+        if (dense && outEnd > outBegin)
+            HIP_TRY(hipMemcpyAsync(out + outBegin, b->dOut.p + outBegin, (outEnd - outBegin) * sizeof(float), hipMemcpyDeviceToHost, s));
+        for (size_t v = 0; !dense && v < nvoices; v++)
+            if (const uint64_t ns = trm_batch_samples_for_frames(b, nframes[v]))
+                HIP_TRY(hipMemcpyAsync(out + out_offset[v], b->dOut.p + out_offset[v], ns * sizeof(float), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipMemcpyAsync(number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 #ifndef TRM_STAMP_LONG
 #define TRM_STAMP_LONG 1600      /* cycles: a step's work above this counts as a long step */
 #endif
-#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0, st_long = 0, st_excess = 0, st_max = 0;
+#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0, st_long = 0, st_excess = 0, st_max = 0; const unsigned long long st_born = __builtin_amdgcn_s_memrealtime();
 #define SUB_DECL unsigned long long sub_t = 0, sub_acc[6] = {0, 0, 0, 0, 0, 0};
 #define SUB_START sub_t = __builtin_readcyclecounter();
 #define SUB_LAP(i_) { unsigned long long n_ = __builtin_readcyclecounter(); sub_acc[i_] += n_ - sub_t; sub_t = n_; }
@@ -79,6 +79,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8] = st_work;                    \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 1] = st_wait;                \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); /* HW_ID */ \
+        A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 3] = st_born;   /* 100 MHz wall clock: when the wave entered its loop ... */ \
+        A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 4] = __builtin_amdgcn_s_memrealtime();   /* ... and left it */ \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 5] = st_long;                \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 6] = st_excess;              \
         A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 7] = st_max;                 \

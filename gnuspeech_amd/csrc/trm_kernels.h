@@ -62,8 +62,9 @@ hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hi
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
 // small-batch form (trm_quad.hip): 16 voices per workgroup, four lanes per voice
 constexpr int kStreamFloats = 192;   // oscillator position, filter memories, 32 samples of FIR / converter history, 4 x 20 tube values
-hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream);
-int tube_quad_kernel_blocks_per_cu();
+// `cus` = the device's compute units: more workgroups than that run the instance that fits two per CU
+hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream, int cus);
+int tube_quad_kernel_blocks_per_cu(int sub);     // sub = blocks per pipeline step of the instance asked about (1 or 2)
 // Down-sampling converter (TRMSampleRateConverter.m:234-297) over tube-rate samples in HBM.
 struct DownArgs {
     const float *tube;            // tube-rate samples incl. 2*pad zeros of flush per voice

@@ -187,12 +187,13 @@ TRM_HD F throat_eval(const Const &C, F thr, F y1)
     return F(C.ta0) * thr + F(C.tb1) * y1;
 }
 
-// One tube sample given the band-pass output `fr` and the throat output `ty` of that sample.
+// One tube sample given the throat output `ty` of that sample and the frication INJECTIONS inA / inB = this part's
+// taps x the band-pass output of that sample (rounds (0, 2) and (1, 3); part 1's idle round 3: the three-way junction's).
 // Returns the tube-rate output in PART 2 (other parts: unspecified).
 template <class F>
-TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F fr, F ty, typename PairOf<F>::type endK,
+TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F ty, typename PairOf<F>::type endK,
                         typename PairOf<F>::type endOnePlus, typename PairOf<F>::type kA, typename PairOf<F>::type kB,
-                        typename PairOf<F>::type tA, typename PairOf<F>::type tB)
+                        typename PairOf<F>::type inA, typename PairOf<F>::type inB)
 {
     typedef typename PairOf<F>::type P;
     const F d = F(C.damping);
@@ -216,10 +217,9 @@ TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F fr, F ty, type
     const P bA = pk_make(S.BB.x, b2), bB = pk_make(b1, b3);        // b0 = B1
 
     // ---- generic junctions (:783-816, :838-846), two rounds per operation
-    const P dd = pk_make(d, d), ff = pk_make(fr, fr);
+    const P dd = pk_make(d, d);
     // T = d b + t (a - b) + tap fr, B = T - d (a - b): kA / kB carry t = (1 + k) d (tube_step)
     const P dfA = aA - bA, dfB = aB - bB;
-    const P inA = tA * ff, inB = tB * ff;
     const P ndd = pk_make(-d, -d);
     const P TA = pk_fma(kA, dfA, dd * bA), TB = pk_fma(kB, dfB, dd * bB);
     S.BA = pk_fma(ndd, dfA, TA);
@@ -259,7 +259,8 @@ TRM_HD F tube_quad_step(QuadState<F> &S, const Const &C, F gin, F sig, F thr, F 
     S.bx2 = S.bx1; S.bx1 = sig; S.by2 = S.by1; S.by1 = fr;
     const F ty = throat_eval(C, thr, S.thY);
     S.thY = ty;
-    return tube_quad_core(S, C, gin, fr, ty, endK, endOnePlus, kA, kB, tA, tB);
+    const typename PairOf<F>::type ff = pk_make(fr, fr);
+    return tube_quad_core(S, C, gin, ty, endK, endOnePlus, kA, kB, tA * ff, tB * ff);
 }
 
 // ================================================================ oscillator, time-slot form

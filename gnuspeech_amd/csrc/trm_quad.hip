@@ -9,11 +9,13 @@
 //   tube             lanes = 4 parts of the tube, junction values crossing a part boundary move by DPP
 //   convert          lane = output time, as in the wide kernel (rows of 32 outputs x 2 voices)
 // so one pass of the instruction streams advances 4 tube samples (a "block") and 256 workgroups cover 4096
-// voices.  One barrier per STEP of kSub = 2 blocks: the feed-forward waves run the step's two blocks as two
-// independent instruction streams (each hides the other's latencies), the tube wave 8 samples in a row.  At step i
-// osc works on the blocks of step i, mix and coef on those of step i-1, the band-pass and throat scans (recurrences
-// that only FEED the tube; they live in feed-forward waves) on those of step i-2, tube on those of step i-4,
-// convert on whatever is complete, metered.  trm_tube_kernel_q<true> is the streaming instance (state in / out).
+// voices.  One barrier per STEP of kSub blocks.  kSub = 2 (batches of at most one workgroup per CU): the feed-forward
+// waves run the step's two blocks as two independent instruction streams (each hides the other's latencies), the
+// tube wave 8 samples in a row; 110 KB of LDS.  kSub = 1 (larger batches): half the hand-off depth, 76 KB of LDS, so
+// that TWO workgroups share a CU and fill each other's issue slots.  At step i osc works on the blocks of step i, mix
+// on those of step i-1, the two coefficient waves and the band-pass and throat scans (recurrences that only FEED
+// the tube; they live in feed-forward waves) on those of step i-2, tube on those of step i-4, convert on whatever
+// is complete, metered.  trm_tube_kernel_q<true, .> is the streaming instance (state in / out).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,14 +24,17 @@
 #include "trm_lane.h"
 #include "trm_quad.h"
 
+// Timing experiments (tools/bench_variants.sh) live behind ONE switch; the product build defines none of them.
+#ifndef TRM_EXPERIMENTS
+#undef TRM_ABL_CVT
+#undef TRM_ABL_SKIP
+#undef TRM_QROLE_PERM
+#undef TRM_THROAT_IN_OSC
+#endif
 #ifndef TRM_ABL_CVT
 #define TRM_ABL_CVT 0
 #endif
-/* where the two scans that feed the tube run: the band-pass in the oscillator wave (1) or the area wave (0), the
-   throat low-pass in the oscillator wave (1) or the mix wave (0) */
-#ifndef TRM_BP_IN_OSC
-#define TRM_BP_IN_OSC 0
-#endif
+/* where the throat low-pass scan runs: the oscillator wave (1) or the mix wave (0) */
 #ifndef TRM_THROAT_IN_OSC
 #define TRM_THROAT_IN_OSC 1
 #endif
@@ -54,10 +59,6 @@ __device__ __forceinline__ uint32_t lds_flag_consume(uint32_t *flag)
 
 constexpr int kQV = 16;              // voices per workgroup
 constexpr int kQB = kSlots;          // tube samples per block = time slots per voice
-constexpr int kSub = 2;              // blocks per pipeline step: the feed-forward waves run two INDEPENDENT blocks per
-                                     // step (their instruction streams interleave and hide each other's latencies), the
-                                     // tube wave 8 samples in a row; half as many barriers
-constexpr int kStepN = kQB * kSub;   // tube samples per step
 constexpr int kQRoles = 6;           // osc, mix, coef x2 (area | frication), tube, convert
 constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
 constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
@@ -65,9 +66,10 @@ constexpr int kOStride = kORing + kOMirror + 4;   // + 32 bytes: a row of lanes 
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
-constexpr int kQBufs = 4 * kSub;    // mix/coef -> tube hand-off buffers: block b lives in buffer b % 8 (at step i the tube stage
-                                     // reads the blocks of step i-4 and the head of step i-3's, the band-pass works on step i-2's,
-                                     // step i-1's are being written)
+// Hand-off depths in steps (x kSub blocks).  Block b of the mix wave's records lives in buffer b % (4 kSub): written
+// during step j+1, scanned during j+2, read by the tube during j+4 (its head during j+3).  The coefficient waves'
+// records live in buffer b % (3 kSub): written during step j+2, read during j+4 (head: j+3).
+constexpr int kXDepth = 4, kKDepth = 3;
 constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS: block B in buffer B % 3
 constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes apart, so that 16 lanes reading 16 rows hit 16 bank groups
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
@@ -75,20 +77,49 @@ constexpr int kQLead = 28;           // tube sample n sits at converter-ring slo
 
 // kStream: the launch is a chunk of a streamed utterance (state restored / saved); a compile-time switch so that
 // the one-shot instance carries none of it.
-template <bool kStream>
-__global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const C, const TubeArgs A)
+// LDS layout of one workgroup, carved out of ONE dynamically sized array: with static __shared__ arrays the compiler
+// knows the size, concludes that two workgroups of six waves are "three waves per SIMD" and pads the kernel's VGPR
+// allocation to 129 registers on purpose (the smallest count that keeps occupancy at three) -- but six waves on four
+// SIMDs put FOUR waves of two co-resident workgroups on one SIMD whenever both start on the same one, 4 x 136
+// registers do not fit 512, and the second workgroup waits for the first to end (measured: 256 workgroups at 0 us, 256
+// at 1030 us).  With the size hidden and four waves per SIMD asked for, the allocation is the 122 registers the code uses.
+template <int kSub>
+struct QuadLds {
+    static constexpr int kXBufs = kXDepth * kSub, kKBufs = kKDepth * kSub, kABufs = 2 * kSub;
+    static constexpr size_t oO = 0;                                                       // float2 [kQV * kOStride]
+    static constexpr size_t oA = oO + sizeof(float2) * kQV * kOStride;                    // float2 [kABufs * kWave]
+    static constexpr size_t oX = oA + sizeof(float2) * kABufs * kWave;                    // float4 [kXBufs * kQB * kXPitch]
+    static constexpr size_t oBP = oX + sizeof(float4) * kXBufs * kQB * kXPitch;           // float4 [kKBufs * kQB * kXPitch]
+    static constexpr size_t oK = oBP + sizeof(float4) * kKBufs * kQB * kXPitch;           // float4 [kKBufs * kQB * kKPitch]
+    static constexpr size_t oY = oK + sizeof(float4) * kKBufs * kQB * kKPitch;            // float  [kQV * kYStride]
+    static constexpr size_t oRows = oY + sizeof(float) * kQV * kYStride;                  // float  [kRowBufs * kCvtCols * kRowPitch]
+    static constexpr size_t oInfo = oRows + sizeof(float) * kRowBufs * kCvtCols * kRowPitch;   // uint4 [kQV]
+    static constexpr size_t oMx = oInfo + sizeof(uint4) * kQV;                            // float  [8 * kWave]
+    static constexpr size_t oNoise = oMx + sizeof(float) * 8 * kWave;                     // float  [kNoiseRing]
+    static constexpr size_t oSync = oNoise + sizeof(float) * kNoiseRing;                  // uint32 [2]
+    static constexpr size_t kBytes = oSync + 16;
+    static_assert(oA % 16 == 0 && oX % 16 == 0 && oBP % 16 == 0 && oK % 16 == 0 && oY % 16 == 0 && oRows % 16 == 0 && oInfo % 16 == 0, "16-byte aligned pieces");
+};
+
+// kSub: blocks per pipeline step (see the top of the file).
+template <bool kStream, int kSub>
+__global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Const C, const TubeArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float2 sO[kQV * kOStride];            // osc -> mix: oscillator reads
-    __shared__ __attribute__((aligned(16))) float2 sA[2 * kSub * kWave];          // osc -> mix: {ax, ah1} per (block & 3, lane)
-    __shared__ __attribute__((aligned(16))) float4 sX[kQBufs * kQB * kXPitch];                 // mix -> tube: {gin, sig, thr} [buf][slot][voice]
-    __shared__ __attribute__((aligned(16))) float4 sBP[kQBufs * 2 * kQB * kXPitch];            // coef -> tube: SharedRecord [buf][half][slot][voice]
-    __shared__ __attribute__((aligned(16))) float4 sK[kQBufs * kQB * kKPitch];     // coef -> tube: part records
-    __shared__ __attribute__((aligned(16))) float sY[kQV * kYStride];             // tube-rate rings
-    __shared__ uint4 sInfo[kQV];
-    __shared__ uint32_t sRowSync[2];     // [0] convert -> mix: first block whose staged rows are still needed; [1] mix -> convert: blocks staged
-    __shared__ float sMx[8 * kWave];
-    __shared__ float sNoise[kNoiseRing];
-    __shared__ __attribute__((aligned(16))) float sRows[kRowBufs * kCvtCols * kRowPitch];   // mix -> convert: coefficient rows of 3 blocks
+    constexpr int kStepN = kQB * kSub;       // tube samples per step
+    typedef QuadLds<kSub> L;
+    constexpr int kXBufs = L::kXBufs, kKBufs = L::kKBufs, kABufs = L::kABufs;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sLds[];
+    float2 *const sO = reinterpret_cast<float2 *>(sLds + L::oO);           // osc -> mix: oscillator reads
+    float2 *const sA = reinterpret_cast<float2 *>(sLds + L::oA);           // osc -> mix: {ax, ah1} per (block % kABufs, lane)
+    float4 *const sX = reinterpret_cast<float4 *>(sLds + L::oX);           // mix -> tube: {gin, sig, thr} [buf][slot][voice]
+    float4 *const sBP = reinterpret_cast<float4 *>(sLds + L::oBP);         // area -> tube: {C8, NC6, 1 + C8, 1 + NC6} [buf][slot][voice]
+    float4 *const sK = reinterpret_cast<float4 *>(sLds + L::oK);           // coef -> tube: part records {transmission | injection}
+    float *const sY = reinterpret_cast<float *>(sLds + L::oY);             // tube-rate rings
+    float *const sRows = reinterpret_cast<float *>(sLds + L::oRows);       // mix -> convert: coefficient rows of 3 blocks
+    uint4 *const sInfo = reinterpret_cast<uint4 *>(sLds + L::oInfo);
+    float *const sMx = reinterpret_cast<float *>(sLds + L::oMx);
+    float *const sNoise = reinterpret_cast<float *>(sLds + L::oNoise);
+    uint32_t *const sRowSync = reinterpret_cast<uint32_t *>(sLds + L::oSync);   // [0] convert -> mix: first block whose staged rows are still needed; [1] mix -> convert: blocks staged
 
     constexpr int kStampRoles = kQRoles;
     (void)kStampRoles;
@@ -97,7 +128,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     // others are paired so that the SIMDs carry about the same work (tools/stage_profile.py)
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifndef TRM_QROLE_PERM
-#define TRM_QROLE_PERM 1, 0, 5, 4, 2, 3      /* mix osc convert tube | coef-area coef-fric */
+#define TRM_QROLE_PERM 1, 5, 0, 4, 2, 3      /* mix convert osc tube | coef-area coef-fric: the frication wave (the longest
+                                                feed-forward role) shares its SIMD with the converter (the shortest), the
+                                                oscillator has one to itself like the tube (profiles/role_perm_r02.txt) */
 #endif
     const int rolePerm[kQRoles] = {TRM_QROLE_PERM};
     int role = 0;
@@ -163,12 +196,10 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             if (throat) Z.thY = st[2];
         }
     };
-    // band-pass (TRMFilters.m:19-29) of block `blk`: input sX.y (mix) and coefficients (fric wave) are in LDS
-    auto bandpass_scan = [&](ScanState &Z, uint32_t blk) {
-        const int b2 = blk % kQBufs;
-        float *const xr = reinterpret_cast<float *>(&sX[(b2 * kQB + part) * kXPitch + vq]);
-        const float sig = xr[1];
-        const float4 bp = sBP[((b2 * 2) * kQB + part) * kXPitch + vq];
+    // band-pass (TRMFilters.m:19-29) of block `blk`: input sX.y (mix wave, in LDS), coefficients bp = this lane's
+    // sample's {2 alpha, 2 beta, 2 gamma}; returns the lane's band-pass output
+    auto bandpass_scan = [&](ScanState &Z, uint32_t blk, const float4 bp) {
+        const float sig = reinterpret_cast<const float *>(&sX[((blk % kXBufs) * kQB + part) * kXPitch + vq])[1];
         const float X = q_take<0, kPart2 | kPart3>(sig, Z.prevSig);         // slots 0, 1 look into the previous block
         const float x2 = q_take<2, kPartAll>(X, X);
         float f = 0.0f;
@@ -183,12 +214,12 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         Z.by1 = q_take<0, kPart0>(Z.by1, Z.ny1);
         Z.by2 = q_take<0, kPart0 | kPart1>(Z.by2, Z.ny2);
         Z.prevSig = sig;
-        xr[1] = f;
         if (streaming) {
             const uint32_t n = blk * kQB + (uint32_t)part;
             if (n + 2u == ntubeLane) { st[4] = f; st[6] = sig; }
             if (n + 1u == ntubeLane) { st[5] = f; st[7] = sig; }
         }
+        return f;
     };
     // throat low-pass (:341, TRMFilters.m:72-77) over this lane's input `thr` of sample m
     auto throat_scan = [&](ScanState &Z, float thr, uint32_t m) {
@@ -228,21 +259,18 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         }
         float2 *const ring = &sO[vq * kOStride];
         ScanState Z;
-        scans_restore(Z, TRM_BP_IN_OSC, TRM_THROAT_IN_OSC);
+        scans_restore(Z, false, TRM_THROAT_IN_OSC);
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
 #pragma unroll
             for (int u = 0; u < kSub; u++) {
-                // the blocks of step i-2: the mix wave's {sig, thr} and the coefficient wave's band-pass were written
-                // during step i-1; the tube wave reads the results from step i+1 on
+                // the blocks of step i-2: the mix wave's {sig, thr} were written during step i-1; the tube wave reads
+                // the result from step i+1 on
                 const uint32_t blk = (step - 2) * kSub + u;
-                if ((TRM_BP_IN_OSC || TRM_THROAT_IN_OSC) && step >= 2 && blk * kQB < nTotal) {
-                    if (TRM_BP_IN_OSC) bandpass_scan(Z, blk);
-                    if (TRM_THROAT_IN_OSC) {
-                        float *const xr = reinterpret_cast<float *>(&sX[((blk % kQBufs) * kQB + part) * kXPitch + vq]);
-                        xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
-                    }
+                if (TRM_THROAT_IN_OSC && step >= 2 && blk * kQB < nTotal) {
+                    float *const xr = reinterpret_cast<float *>(&sX[((blk % kXBufs) * kQB + part) * kXPitch + vq]);
+                    xr[2] = throat_scan(Z, xr[2], blk * kQB + (uint32_t)part);
                 }
             }
 #pragma unroll
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                 const uint32_t slot = (oblk * kQB + (uint32_t)part) & (kORing - 1);
                 ring[slot] = make_float2(wa, wb);
                 if (slot < (uint32_t)kOMirror) ring[slot + kORing] = make_float2(wa, wb);
-                sA[(oblk & 3) * kWave + lane] = make_float2((float)axd, ah1);
+                sA[(oblk % kABufs) * kWave + lane] = make_float2((float)axd, ah1);
               }
             }
             STAMP_MID
@@ -356,7 +384,7 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             for (int u = 0; u < kSub; u++) {
               const uint32_t blk = (step - 1) * kSub + u;
               if (step >= 1 && blk * kQB < nTotal) {
-                const int buf = blk & 3, xbuf = blk % kQBufs;
+                const int buf = blk % kABufs, xbuf = blk % kXBufs;
                 const uint32_t n0 = blk * kQB;
                 if ((n0 & (kNoiseHalf - 1)) == 0 && n0 > 0) {
                     // entering a noise half: it was requested one half ago; refill the other half
@@ -399,12 +427,14 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_STORE(role)
         dma_wait_all();
     } else if (role == 2 || role == 3) {
-        // ------------------------------------------------------------ coef: block i-1 at step i, lane = (voice, slot).
-        // Two waves share the stage by FUNCTION (both are stateless in time): role 2 turns radii and velum into
-        // scattering coefficients, role 3 turns the frication tracks into taps and the band-pass.
+        // ------------------------------------------------------------ coef: block i-2 at step i, lane = (voice, slot).
+        // Two waves share the stage by FUNCTION: role 2 turns radii and velum into the junctions' transmission factors
+        // (stateless in time), role 3 turns the frication tracks into taps and band-pass coefficients, runs the band-pass
+        // over the mix wave's noise signal (written during step i-1) and hands the tube the INJECTIONS tap x band-pass
+        // output: the tube wave neither sees the band-pass nor multiplies by taps.
         const bool area = role == 2;
         ScanState Z;
-        scans_restore(Z, area && !TRM_BP_IN_OSC, false);
+        scans_restore(Z, !area, false);
         CoefTrack T;
         float prev[16], cur[16], nxt[16];
         uint32_t per = 0, j = (uint32_t)part;
@@ -419,9 +449,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
             STAMP_BEGIN
 #pragma unroll
             for (int u = 0; u < kSub; u++) {
-              const uint32_t blk = (step - 1) * kSub + u;
-              if (step >= 1 && blk * kQB < nTotal) {
-                const int buf = blk % kQBufs;
+              const uint32_t blk = (step - 2) * kSub + u;
+              if (step >= 2 && blk * kQB < nTotal) {
+                const int buf = blk % kKBufs;
                 if (j >= CP) {
                     j -= CP;
                     per++;
@@ -439,19 +469,17 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
                     pack_part_kk(K, C, R);
                     pack_shared_end(K, C, H);
                     for (int p = 0; p < 4; p++) dst[p * 4] = make_float4(R[p].kk[0], R[p].kk[1], R[p].kk[2], R[p].kk[3]);
-                    sBP[((buf * 2 + 1) * kQB + part) * kXPitch + vq] = make_float4(H.endK[0], H.endK[1], H.endOnePlus[0], H.endOnePlus[1]);
+                    sBP[(buf * kQB + part) * kXPitch + vq] = make_float4(H.endK[0], H.endK[1], H.endOnePlus[0], H.endOnePlus[1]);
                 } else {
                     coef_sample_fric(K, T, C, (int)j);
                     pack_part_tp(K, R);
                     pack_shared_bp(K, H);
-                    for (int p = 0; p < 4; p++) dst[kWave + p * 4] = make_float4(R[p].tp[0], R[p].tp[1], R[p].tp[2], R[p].tp[3]);
-                    sBP[((buf * 2) * kQB + part) * kXPitch + vq] = make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f);
+                    const float f = bandpass_scan(Z, blk, make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f));
+                    for (int p = 0; p < 4; p++) dst[kWave + p * 4] = make_float4(R[p].tp[0] * f, R[p].tp[1] * f, R[p].tp[2] * f, R[p].tp[3] * f);
                 }
                 j += kQB;
               }
             }
-            for (int u = 0; u < kSub; u++)
-                if (!TRM_BP_IN_OSC && area && step >= 2 && ((step - 2) * kSub + u) * kQB < nTotal) bandpass_scan(Z, (step - 2) * kSub + u);
             STAMP_MID
             step_barrier();
             STAMP_END
@@ -459,6 +487,9 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         STAMP_STORE(role)
     } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
+        // the only serial role: where it shares a SIMD (two workgroups on a CU) its instructions go first (8192 voices:
+        // 4.54 -> 4.33 ms, profiles/role_perm_r02.txt)
+        __builtin_amdgcn_s_setprio(3);
         QuadState<float> S;
         quad_reset(S);
         float *const stTube = streaming ? st + 104 + 20 * part : nullptr;
@@ -478,24 +509,24 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
         };
         float4 *const ring = reinterpret_cast<float4 *>(&sY[vq * kYStride]);
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
-        // one sample's inputs: {gin, band-pass output, throat output}, end coefficients, this part's record
+        // one sample's inputs: {gin, -, throat output}, end coefficients, this part's record {transmission | injection}
         struct In { float4 x, e4, k4, t4; };
         auto load_in = [&](uint32_t blk, int s) {
-            const int buf = blk % kQBufs;
+            const int buf = blk % kKBufs;
             In r;
-            r.x = sX[(buf * kQB + s) * kXPitch + vq];
-            r.e4 = sBP[((buf * 2 + 1) * kQB + s) * kXPitch + vq];
+            r.x = sX[((blk % kXBufs) * kQB + s) * kXPitch + vq];
+            r.e4 = sBP[(buf * kQB + s) * kXPitch + vq];
             const float4 *rec = &sK[(buf * kQB + s) * kKPitch + lane];
             r.k4 = rec[0];
             r.t4 = rec[kWave];
             return r;
         };
         auto step_one = [&](const In &r) {
-            return tube_quad_core<float>(S, C, r.x.x, r.x.y, r.x.z, v2f_t{r.e4.x, r.e4.y}, v2f_t{r.e4.z, r.e4.w},
+            return tube_quad_core<float>(S, C, r.x.x, r.x.z, v2f_t{r.e4.x, r.e4.y}, v2f_t{r.e4.z, r.e4.w},
                                          v2f_t{r.k4.x, r.k4.y}, v2f_t{r.k4.z, r.k4.w}, v2f_t{r.t4.x, r.t4.y},
                                          v2f_t{r.t4.z, r.t4.w});
         };
-        // The blocks of step i-4 at step i (their band-pass output was written during step i-2).  A block's first
+        // The blocks of step i-4 at step i (their coefficient records were written during step i-2).  A block's first
         // sample's inputs are fetched behind the last sample of the block before it (for the step's first block:
         // during step i-1), the other three land behind the first sample's arithmetic: no LDS latency is exposed.
         In head;
@@ -736,22 +767,41 @@ __global__ __launch_bounds__(kWave *kQRoles) void trm_tube_kernel_q(const Const 
     }
 }
 
-hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream)
+// `cus`: the device's compute units.  A batch of more workgroups than that runs the instance that fits two of them on
+// a CU (kSub = 1); up to one workgroup per CU the instance with two independent blocks per step (kSub = 2).
+template <bool kStream, int kSub>
+static hipError_t launch_instance(const Const &c, const TubeArgs &a, hipStream_t stream, uint32_t grid)
 {
-    if (a.nvoices == 0) return hipSuccess;
-    uint32_t grid = (a.nvoices + kQV - 1) / kQV;
-    if (a.stream_state)
-        hipLaunchKernelGGL(trm_tube_kernel_q<true>, dim3(grid), dim3(kWave * kQRoles), 0, stream, c, a);
-    else
-        hipLaunchKernelGGL(trm_tube_kernel_q<false>, dim3(grid), dim3(kWave * kQRoles), 0, stream, c, a);
+    // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
+    static bool allowed[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 16 && !allowed[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(trm_tube_kernel_q<kStream, kSub>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)QuadLds<kSub>::kBytes);
+        if (e != hipSuccess) return e;
+        allowed[dev] = true;
+    }
+    hipLaunchKernelGGL((trm_tube_kernel_q<kStream, kSub>), dim3(grid), dim3(kWave * kQRoles), QuadLds<kSub>::kBytes, stream, c, a);
     return hipGetLastError();
 }
 
-int tube_quad_kernel_blocks_per_cu()
+hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream, int cus)
+{
+    if (a.nvoices == 0) return hipSuccess;
+    uint32_t grid = (a.nvoices + kQV - 1) / kQV;
+    if (a.stream_state) return launch_instance<true, 2>(c, a, stream, grid);
+    if (cus > 0 && grid > (uint32_t)cus) return launch_instance<false, 1>(c, a, stream, grid);
+    return launch_instance<false, 2>(c, a, stream, grid);
+}
+
+int tube_quad_kernel_blocks_per_cu(int sub)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel_q<false>, kWave * kQRoles, 0) != hipSuccess) return -1;
-    return n;
+    hipError_t e = sub == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel_q<false, 1>, kWave * kQRoles, QuadLds<1>::kBytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel_q<false, 2>, kWave * kQRoles, QuadLds<2>::kBytes);
+    return e == hipSuccess ? n : -1;
 }
 
 }  // namespace trm

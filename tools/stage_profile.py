@@ -51,6 +51,22 @@ if quad:
     for row in simd:
         pat[tuple(row)] = pat.get(tuple(row), 0) + 1
     print("  SIMD of (%s): %s" % (", ".join(names), "; ".join("%s x%d" % ("".join(map(str, k)), n) for k, n in sorted(pat.items(), key=lambda kv: -kv[1])[:8])))
+if quad:
+    # which workgroups shared a CU (HW_ID: CU [11:8], SH [12], SE [15:13]; the XCD is not in HW_ID, so up to 8 CUs
+    # alias one key: read the PATTERNS of the tube wave's SIMD among the workgroups of a key, not the counts)
+    cu = (hw[:, 4] >> 8) & 0xFF
+    tube_simd = simd[:, 4]
+    print("  tube wave's SIMD, histogram over workgroups: %s" % np.bincount(tube_simd, minlength=4).tolist())
+    # when did each workgroup's tube wave run (100 MHz clock)?  co-resident workgroups start together
+    born = buf.reshape(nwg, NR, 8)[:, 4, 3].astype(np.float64); died = buf.reshape(nwg, NR, 8)[:, 4, 4].astype(np.float64)
+    t0 = born.min()
+    print("  tube wave start (us after the first): quartiles %s; run time (us): median %.0f; whole launch %.0f us" % (
+        np.percentile((born - t0) / 100.0, [0, 25, 50, 75, 100]).round(0).tolist(), np.median(died - born) / 100.0, (died.max() - t0) / 100.0))
+    hist, edges = np.histogram((born - t0) / 100.0, bins=12)
+    print("  start-time histogram (us): " + ", ".join("%.0f:%d" % (edges[i], hist[i]) for i in range(len(hist)) if hist[i]))
+    rt = (died - born) / 100.0
+    print("  run time by start group: " + ", ".join("start<%.0f: n=%d median run %.0f us" % (hi, int(((born - t0) / 100.0 < hi).sum()), float(np.median(rt[(born - t0) / 100.0 < hi]))) for hi in (10.0,)) +
+          "; later starters: n=%d median run %.0f us" % (int(((born - t0) / 100.0 >= 10.0).sum()), float(np.median(rt[(born - t0) / 100.0 >= 10.0]))))
 if not quad:
     sub = np.median(s[:, 5, 2:], axis=0) / ntube
     print("  convert0 sub-phases (cycles per tube sample): reads-issue %.0f, readlanes %.0f, dot %.0f, stores %.0f, tile+block-end %.0f" % tuple(sub[:5]))
