@@ -40,7 +40,7 @@ class TrmIntonation(C.Structure):
     """trm_intonation (include/trm_c_api.h): MMIntonation's switches + pitch mean + time range."""
     _fields_ = [("useMicroIntonation", C.c_int32), ("useMacroIntonation", C.c_int32), ("useSmoothIntonation", C.c_int32),
                 ("useDrift", C.c_int32), ("driftDeviation", C.c_float), ("driftCutoff", C.c_float), ("pitchMean", C.c_double),
-                ("timeQuantization", C.c_uint32), ("startTime_ms", C.c_uint32), ("endTime_ms", C.c_uint32)]
+                ("timeQuantization", C.c_uint32), ("startTime_ms", C.c_uint32), ("endTime_ms", C.c_uint32), ("driftSeed", C.c_float)]
 
 
 class TrmDerived(C.Structure):
@@ -63,7 +63,7 @@ EXPORTS = [
     "trm_shard_voices", "trm_multi_create", "trm_multi_destroy", "trm_multi_synthesize_host", "trm_multi_synthesize_host_int16",
     "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
     "trm_stream_push", "trm_stream_finish",
-    "trm_events_count_frames", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
+    "trm_events_count_frames", "trm_drift_seed_after", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
     "trm_batch_set_kernel", "trm_batch_last_kernel",
     "trm_batch_kernel_time_ms", "trm_batch_set_timing", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
 ]
@@ -142,6 +142,8 @@ def lib():
     L.trm_stream_push.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_uint32), vp]
     L.trm_stream_finish.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), vp]
     L.trm_events_count_frames.argtypes = [vp, C.c_size_t, C.POINTER(TrmIntonation), C.POINTER(C.c_size_t)]
+    L.trm_drift_seed_after.argtypes = [C.c_float, C.c_size_t]
+    L.trm_drift_seed_after.restype = C.c_float
     L.trm_batch_generate_frames_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.POINTER(TrmIntonation), vp, vp, vp, vp]
     L.trm_batch_generate_frames_host.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(TrmIntonation), vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.trm_write_sound_file.argtypes = [C.POINTER(TrmInputParams), vp, C.c_size_t, C.c_float, C.c_char_p]

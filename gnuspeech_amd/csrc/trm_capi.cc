@@ -14,6 +14,7 @@
 #include <string>
 #include <utility>
 #include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/trm_c_api.h"
@@ -822,10 +823,34 @@ static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frame
         return rc;
     if (out16 && (rc = b->dOut16.reserve(outEnd * ch + 1))) return rc;
     hipStream_t s = b->stream;
+    // Ragged batches: the kernels' voice index is put in order of decreasing length, so that the voices of a workgroup
+    // (16 or 64 consecutive indices) end together instead of every workgroup lasting as long as the longest voice of
+    // the batch: a workgroup that ends early frees its CU for the next one.  Only the three index arrays are permuted
+    // (frames and PCM stay where the caller's offsets put them); the per-voice results are put back in caller order.
+    std::vector<uint32_t> perm;
+    std::vector<uint64_t> pFrameOff, pOutOff;
+    std::vector<uint32_t> pNFrames, pNs;
+    std::vector<float> pMx;
+    {
+        bool sorted = true;
+        for (size_t v = 1; v < nvoices && sorted; v++) sorted = nframes[v] <= nframes[v - 1];
+        if (!sorted && nvoices > 16) {
+            perm.resize(nvoices);
+            for (size_t v = 0; v < nvoices; v++) perm[v] = (uint32_t)v;
+            std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return nframes[x] > nframes[y]; });
+            pFrameOff.resize(nvoices); pOutOff.resize(nvoices); pNFrames.resize(nvoices); pNs.resize(nvoices); pMx.resize(nvoices);
+            for (size_t i = 0; i < nvoices; i++) {
+                pFrameOff[i] = frame_offset[perm[i]];
+                pOutOff[i] = out_offset[perm[i]];
+                pNFrames[i] = nframes[perm[i]];
+            }
+        }
+    }
+    const bool permuted = !perm.empty();
     HIP_TRY(hipMemcpyAsync(b->dFrames.p, frames, frameRows * 16 * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(b->dFrameOff.p, frame_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(b->dOutOff.p, out_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(b->dNFrames.p, nframes, nvoices * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->dFrameOff.p, permuted ? pFrameOff.data() : frame_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->dOutOff.p, permuted ? pOutOff.data() : out_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->dNFrames.p, permuted ? pNFrames.data() : nframes, nvoices * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     rc = trm_batch_synthesize_device(b, nvoices, b->dFrames.p, b->dFrameOff.p, b->dNFrames.p, maxFrames, b->dOut.p,
                                      b->dOutOff.p, b->dNSamples.p, b->dMax.p, s);
     if (rc) return rc;
@@ -845,9 +870,13 @@ static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frame
             if (const uint64_t ns = trm_batch_samples_for_frames(b, nframes[v]))
                 HIP_TRY(hipMemcpyAsync(out + out_offset[v], b->dOut.p + out_offset[v], ns * sizeof(float), hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(hipMemcpyAsync(number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(permuted ? pNs.data() : number_samples, b->dNSamples.p, nvoices * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(permuted ? pMx.data() : max_sample, b->dMax.p, nvoices * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; permuted && i < nvoices; i++) {
+        number_samples[perm[i]] = pNs[i];
+        max_sample[perm[i]] = pMx[i];
+    }
     return TRM_OK;
 }
 
@@ -994,6 +1023,17 @@ int trm_multi_synthesize_host_int16(trm_multi *m, size_t nvoices, const float *f
 }
 
 // ------------------------------------------------------------------ control-track generation
+float trm_drift_seed_after(float seed, size_t ngenerated)
+{
+    // MMDriftGenerator.m:65-70 in float, one rounding per operation (x86-64 semantics, like the kernel and the oracle)
+    volatile float sd = seed != 0.0f ? seed : 0.7892347f;
+    for (size_t i = 0; i < ngenerated; i++) {
+        volatile float temp = sd * 377.0f;
+        sd = temp - (float)(int32_t)temp;
+    }
+    return sd;
+}
+
 int trm_events_count_frames(const uint32_t *times, size_t n, const trm_intonation *s, size_t *nframes)
 {
     if (!s || !nframes || (n && !times)) return fail(TRM_EINVAL, "null argument");

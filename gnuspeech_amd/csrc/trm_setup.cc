@@ -12,7 +12,6 @@ namespace trm {
 
 namespace {
 
-constexpr int kLimit = 200;            // COEFFICIENT_LIMIT, TRMFIRFilter.m:13
 constexpr int kSrcLen = 13 * 256;      // FILTER_LENGTH, TRMSampleRateConverter.m:20
 
 double amplitude(double db)            // TRMUtility.m:26-41
@@ -36,82 +35,18 @@ double izero(double x)                 // TRMUtility.m:50-66
     return sum;
 }
 
-// Best rational approximation with bounded denominator (TRMFIRFilter.m:265-310).
-void rational(double number, int &order, int &num, int &den)
-{
-    if (order <= 0) { num = den = 0; order = -1; return; }
-    double frac = fabs(number - (int)number);
-    int omax = 2 * order > kLimit ? kLimit : 2 * order;
-    int modulus = 0;
-    double best = 1.0;
-    for (int i = order; i <= omax; i++) {
-        double ps = i * frac;
-        int ip = (int)(ps + 0.5);
-        double e = fabs((ps - ip) / i);
-        if (e < best) { best = e; modulus = ip; den = i; }
-    }
-    num = (int)fabs(number) * den + modulus;
-    if (number < 0) num = -num;
-    order = den - 1;
-    if (num == den) { den = omax; order = num = den - 1; }
-}
-
 }  // namespace
 
-// Maximally-flat linear-phase low-pass design (TRMFIRFilter.m:161-233), then trim (:236-244)
-// and mirror into taps (:73-83).
-int design_fir(double beta, double gamma, double cutoff, std::vector<double> &taps)
-{
-    taps.clear();
-    if (beta <= 0.0 || beta >= 0.5) return -1;
-    double bmin = 2.0 * beta < 1.0 - 2.0 * beta ? 2.0 * beta : 1.0 - 2.0 * beta;
-    if (gamma <= 0.0 || gamma >= bmin) return -2;
-    int nt = (int)(1.0 / (4.0 * gamma * gamma));
-    if (nt > 160) return -3;
-    double ac = (1.0 + cos(2.0 * M_PI * beta)) / 2.0;
-    int numer = 0, np = 0;
-    rational(ac, nt, numer, np);
-    int n = 2 * np - 1;
-    if (numer == 0) numer = 1;
-    std::vector<double> a(kLimit + 2, 0.0), c(kLimit + 2, 0.0), coef(kLimit + 2, 0.0);
-    c[1] = a[1] = 1.0;
-    int ll = nt - numer;
-    for (int i = 2; i <= np; i++) {
-        double sum = 1.0;
-        c[i] = cos(2.0 * M_PI * ((double)(i - 1) / (double)n));
-        double x = (1.0 - c[i]) / 2.0, y = x;
-        if (numer == nt) continue;
-        for (int j = 1; j <= ll; j++) {
-            double z = y;
-            if (numer != 1)
-                for (int jj = 1; jj <= numer - 1; jj++) z *= 1.0 + (double)j / (double)jj;
-            y *= x;
-            sum += z;
-        }
-        a[i] = sum * pow(1.0 - x, numer);
-    }
-    for (int i = 1; i <= np; i++) {
-        coef[i] = a[1] / 2.0;
-        for (int j = 2; j <= np; j++) {
-            int m = ((i - 1) * (j - 1)) % n;
-            if (m > nt) m = n - m;
-            coef[i] += c[m + 1] * a[j];
-        }
-        coef[i] *= 2.0 / (double)n;
-    }
-    int ncoef = np;
-    for (int i = np; i > 0; i--)
-        if (fabs(coef[i]) >= fabs(cutoff)) { ncoef = i; break; }
-    int ntaps = 2 * ncoef - 1;
-    taps.resize(ntaps);
-    int inc = -1, ptr = ncoef;
-    for (int i = 0; i < ntaps; i++) {
-        taps[i] = coef[ptr];
-        ptr += inc;
-        if (ptr <= 0) { ptr = 2; inc = 1; }
-    }
-    return ntaps;
-}
+// The oscillator's 49-tap FIR: TRMFIRFilter.h:7-9 fixes beta = 0.2, gamma = 0.1, cutoff = 1e-8, so the maximally-flat
+// design (TRMFIRFilter.m:161-233, trimmed and mirrored :73-83, :236-244) has ONE outcome: c[0..24] below, c[48 - i] = c[i].
+// The design routine itself lives in the oracle (oracle/trm_oracle.c: maximally_flat); tests/test_quad_model.py checks
+// this table against the taps the reference binary computed (tests/golden/*.npz: firCoef).
+const double kFirHalf[kFirUnique] = {
+    1.0887157865533967e-08, 7.3133299513665035e-08, 2.137841904426972e-07, -6.5322947036563118e-08, -2.4300136304004587e-06,
+    -6.267564867199802e-06, 2.2354964101677552e-06, 4.3261082316484397e-05, 6.9699584503931649e-05, -8.6968794272942906e-05,
+    -0.00043243790948125553, -0.00028644112282104019, 0.0011316111860893143, 0.0023296835220954727, -0.00061607377823225985,
+    -0.0070911561060204289, -0.0059227989476883834, 0.011204567485223504, 0.024723951583638423, -0.0013632376466076977,
+    -0.056044214360539933, -0.051247637455809028, 0.087853092781387032, 0.2965041881371811, 0.39847427941239039};
 
 void build_src_h(std::vector<double> &h, std::vector<double> &dh)
 {
@@ -213,10 +148,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
         d.phaseIncrement = (uint32_t)rint(d.sampleRateRatio * 65536.0);  // :92
         d.padSize = (int32_t)((float)13 / rounded) + 1;                  // :96
     }
-    std::vector<double> taps;
-    int nt = design_fir(0.2, 0.1, 0.00000001, taps);                     // TRMFIRFilter.h:7-9
-    if (nt != kFirTaps) return TRM_EFIR;
-    d.firTaps = nt;
+    d.firTaps = kFirTaps;                                                // TRMFIRFilter.h:7-9: always the same 49
 
     c.controlPeriod = d.controlPeriod;
     c.sampleRate = d.sampleRate;
@@ -256,7 +188,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     c.invDiv1 = c.tableDiv1 > 0 ? (float)(1.0 / c.tableDiv1) : 0.0f;
     c.tnDelta = rint(512 * ((p.tnMax - p.tnMin) / 100.0));
     c.basicIncrement = 512.0 / (double)d.sampleRate;
-    for (int i = 0; i < kFirUnique; i++) c.fir[i] = (float)taps[i];
+    for (int i = 0; i < kFirUnique; i++) c.fir[i] = (float)kFirHalf[i];
     c.timeRegisterIncrement = d.timeRegisterIncrement;
     c.phaseIncrement = d.phaseIncrement;
     c.padSize = d.padSize;

@@ -16,8 +16,7 @@ namespace trm {
 // TRM_OK or TRM_EINVAL_LENGTH / TRM_EFIR / TRM_ERANGE.
 int build_const(const trm_input_params &p, Const &c, trm_derived &d);
 
-// 49-tap oscillator FIR (TRMFIRFilter.m:37-98,161-310).  Returns tap count (<0 on failure).
-int design_fir(double beta, double gamma, double cutoff, std::vector<double> &taps);
+extern const double kFirHalf[kFirUnique];      // the 25 distinct taps of the oscillator FIR (trm_setup.cc)
 
 // h[] / deltaH[] of the converter (TRMSampleRateConverter.m:110-131), 3328 doubles each.
 void build_src_h(std::vector<double> &h, std::vector<double> &dh);

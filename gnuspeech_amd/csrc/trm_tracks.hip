@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kWave) void trm_tracks_kernel(const TrackArgs A)
     if (startTime == 0 && endTime == 0) endTime = ~0ull;    // :892-894
 
     // MMDriftGenerator -init / -configureWithDeviation:sampleRate:lowpassCutoff: (MMDriftGenerator.m:27-58)
-    float dPitchDeviation = 0.f, dPitchOffset = 0.f, dA0 = 0.f, dB1 = 0.f, dSeed = 0.7892347f, dPrev = 0.f;
+    // (the seed belongs to the EventList, not to the utterance: driftSeed carries it over, MMDriftGenerator.m:41-58)
+    float dPitchDeviation = 0.f, dPitchOffset = 0.f, dA0 = 0.f, dB1 = 0.f, dSeed = s.driftSeed != 0.0f ? s.driftSeed : 0.7892347f, dPrev = 0.f;
     if (s.useDrift) {                                       // :901-905
         const float sampleRate = (float)(1000u / (s.timeQuantization ? s.timeQuantization : 4u));
         float cutoff = s.driftCutoff;

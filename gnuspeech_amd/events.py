@@ -39,7 +39,7 @@ class MMIntonation:
         self.driftCutoff = 4.0
 
 
-def intonation_struct(intonation, pitch_mean, time_quantization=4, start_ms=0, length_ms=0):
+def intonation_struct(intonation, pitch_mean, time_quantization=4, start_ms=0, length_ms=0, drift_seed=0.0):
     s = TrmIntonation()
     s.useMicroIntonation = int(bool(intonation.shouldUseMicroIntonation))
     s.useMacroIntonation = int(bool(intonation.shouldUseMacroIntonation))
@@ -51,6 +51,7 @@ def intonation_struct(intonation, pitch_mean, time_quantization=4, start_ms=0, l
     s.timeQuantization = int(time_quantization)
     s.startTime_ms = int(start_ms)
     s.endTime_ms = int(start_ms + length_ms) if length_ms else 0        # NSMaxRange; length 0 = everything (:892-894)
+    s.driftSeed = float(drift_seed)
     return s
 
 
@@ -60,6 +61,7 @@ class EventList:
         self.intonation = MMIntonation()
         self.pitchMean = pitch_mean                    # model.synthesisParameters.pitch (EventList.m:983)
         self.timeQuantization = time_quantization
+        self.driftSeed = 0.0                           # the list's drift generator: 0 = not used yet (MMDriftGenerator.m:27-35)
 
     def arrays(self):
         times = np.array([e.time for e in self.events], dtype=np.uint32)
@@ -67,7 +69,7 @@ class EventList:
         return times, np.ascontiguousarray(values)
 
     def settings(self, start_ms=0, length_ms=0):
-        return intonation_struct(self.intonation, self.pitchMean, self.timeQuantization, start_ms, length_ms)
+        return intonation_struct(self.intonation, self.pitchMean, self.timeQuantization, start_ms, length_ms, self.driftSeed)
 
     def count_frames(self, start_ms=0, length_ms=0):
         times, _ = self.arrays()
@@ -88,6 +90,10 @@ class EventList:
         check(lib().trm_batch_generate_frames_host(batch._h, times.ctypes.data, values.ctypes.data, len(times), C.byref(s),
                                                    out.ctypes.data, cap, C.byref(n)))
         frames = out[:n.value]
+        if self.intonation.shouldUseDrift:
+            # the generator belongs to the list and keeps its seed from one utterance to the next (EventList.m:105-106,
+            # 903; MMDriftGenerator.m:41-58): one -generateDrift per 4 ms step, whatever the time range
+            self.driftSeed = float(lib().trm_drift_seed_after(self.driftSeed, self.count_frames()))
         if synthesizer is not None:
             for row in frames:
                 synthesizer.addParameters(TRMParameters(row))

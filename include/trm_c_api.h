@@ -258,7 +258,17 @@ typedef struct trm_intonation {
     uint32_t timeQuantization;     /* ms; the drift generator's rate is 1000 / this        (EventList.m:903) */
     uint32_t startTime_ms;         /* the time range: frames are emitted for start <= t <= end; */
     uint32_t endTime_ms;           /*   end == 0 and start == 0 means "everything"         (EventList.m:892-899) */
+    float   driftSeed;             /* the drift generator's seed at the start of this utterance; 0 = MMDriftGenerator's
+                                    * initial 0.7892347 (a fresh EventList).  The reference keeps ONE generator per EventList
+                                    * and only -init sets its seed ("And seed is not changed...", MMDriftGenerator.m:41-58):
+                                    * the second utterance of a list continues the sequence.  A caller reproduces that by
+                                    * passing trm_drift_seed_after(seed, frames generated) of the utterance before. */
 } trm_intonation;
+
+/* The drift generator's seed after `ngenerated` calls of -generateDrift from `seed` (0 = the initial seed): one call per
+ * 4 ms step of -generateOutputInTimeRange: whatever the time range, i.e. trm_events_count_frames() with start = end = 0
+ * (MMDriftGenerator.m:65-78, EventList.m:970-977). */
+float trm_drift_seed_after(float seed, size_t ngenerated);
 
 /* Number of frames the generator emits for an event list with these event times (exact: follows the
  * loop's time stepping, EventList.m:979-1027).  nevents < 2 -> 0 (the reference indexes event 1). */

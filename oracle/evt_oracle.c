@@ -87,6 +87,7 @@ int trm_oracle_generate_frames(const uint32_t *times, const double *values, size
 
     drift_t drift;
     drift_init(&drift);
+    if (s->driftSeed != 0.0f) drift.seed = s->driftSeed;          /* the EventList's generator continues (MMDriftGenerator.m:41-58) */
     if (s->useDrift)                                              /* :901-905 */
         drift_configure(&drift, s->driftDeviation, (float)(1000u / (s->timeQuantization ? s->timeQuantization : 4u)), s->driftCutoff);
 

@@ -19,9 +19,15 @@
  *    drains that buffer after every dataFill, so converter outputs are fp32-rounded;
  *    numberSamples and maximumSampleValue are read as the doubles/longs tube.c keeps.
  *
- * usage: tube_ref <case.bin> <out.bin>
+ * usage: tube_ref <case.bin> <out.bin> [tract]
  *   case.bin = trm_input_params | uint64 nframes | nframes*16 doubles
  *   out.bin  = see write_out() below
+ *
+ * `tract`: TRAcT's OWN sample loop instead (tube.c:1096-1190, its synthesize() thread body, one iteration per
+ * sample): none of the four divergences is neutralised.  tube.c has no frame input -- its GUI writes `current`
+ * whenever a slider moves -- so the driver holds frame f for the whole control period f (parameters STEP at the
+ * period boundaries, no interpolation), keeps tube.c's own setFricationTaps() (x10, tube.c:1371) and multiplies the
+ * tube-rate sample by 100 before dataFill (tube.c:1177).  This is the golden for shim/tract_tube.c and the streams.
  */
 #include <math.h>
 #include <stdint.h>
@@ -75,7 +81,8 @@ static void drain(void)
 
 int main(int argc, char **argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: %s case.bin out.bin\n", argv[0]); return 2; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s case.bin out.bin [tract]\n", argv[0]); return 2; }
+    const int tract = argc == 4 && !strcmp(argv[3], "tract");
     FILE *fi = fopen(argv[1], "rb");
     if (!fi) { perror("case"); return 2; }
     trm_input_params p;
@@ -109,6 +116,7 @@ int main(int argc, char **argv)
         for (int i = 0; i < 16; i++) {                       /* TRMTubeModel.m:611-672 */
             cur[i] = prev_in[i];
             delta[i] = (cur_in[i] - cur[i]) / (double)controlPeriod;
+            if (tract) { cur[i] = cur_in[i]; delta[i] = 0.0; }   /* TRAcT: the set the GUI left in `current`, held */
         }
         for (int j = 0; j < controlPeriod; j++) {
             *getGlotPitch() = cur[0]; *getGlotVol() = cur[1]; *getAspVol() = cur[2]; *getFricVol() = cur[3];
@@ -121,7 +129,7 @@ int main(int argc, char **argv)
             double ah1 = amplitude(cur[2]);
             calculateTubeCoefficients();                     /* :298 */
             setFricationTaps();                              /* :299 (x10 variant) */
-            {
+            if (!tract) {
                 double ref_taps[8], amp = amplitude(cur[3]);
                 memcpy(ref_taps, fricationTap, sizeof ref_taps);
                 int ip = (int)cur[4];
@@ -153,6 +161,7 @@ int main(int argc, char **argv)
                 sig = lp_noise;
             sig = vocalTract(((pulse + (ah1 * sig)) * 0.125), bandpassFilter(sig)); /* :336-337 */
             sig += throat(pulse * 0.125);                    /* :341 (gain inside, tube.c:1716) */
+            if (tract) sig = sig * 100;                      /* tube.c:1177 */
             tube[ntube++] = sig;
             dataFill(sig);                                   /* :346 */
             drain();

@@ -193,6 +193,12 @@ extern "C" int trm_emul_synthesize_quad(const trm_input_params *p, const float *
     return TRM_OK;
 }
 
+// the product's FIR taps (trm_setup.cc: kFirHalf) as the kernels get them: c[0..24]
+extern "C" void trm_emul_fir_half(double *out)
+{
+    for (int i = 0; i < kFirUnique; i++) out[i] = kFirHalf[i];
+}
+
 // tube_quad_step against tube_step on random state/coefficients: returns the number of mismatching
 // values over `iters` steps (0 = the four-part data movement is exact).
 extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, unsigned seed)

@@ -135,3 +135,46 @@ def golden_cases():
     p["tp"] = 35.0; p["tnMin"] = 20.0; p["tnMax"] = 40.0; p["breathiness"] = 4.0
     cases["female_15cm_stereo"] = (p, rows[200:260].copy())
     return cases
+
+
+# ---------------------------------------------------------------- TRAcT's own loop
+def tract_shim_params():
+    """shim/tract_tube.c's utterance-rate globals = Applications/TRAcT/tube.c:326-352 (what the program starts with)."""
+    return dict(outputFileFormat=1, outputRate=44100.0, controlRate=100.0, volume=60.0, channels=2, balance=0.0, waveform=0,
+                tp=35.0, tnMin=16.0, tnMax=40.0, breathiness=2.5, length=17.0, temperature=32.0, lossFactor=0.8, apScale=2.5,
+                mouthCoef=4000.0, noseCoef=4000.0, noseRadius=[1.35, 1.35, 1.7, 1.7, 1.3, 0.9], throatCutoff=1500.0,
+                throatVol=6.0, usesModulation=1, mixOffset=48.0)
+
+
+TRACT_SHIM_FRAME = [-0.0, 60.0, 0.0, 0.0, 8.0, 5000.0, 250.0, 0.8, 1.67, 1.905, 1.985, 0.81, 0.495, 0.73, 1.485, 0.0]
+TRACT_STEP_FRAME = 69          # the control period from which radius 7 is 0.4 (as the GUI's slider would leave it)
+
+
+def tract_mode_cases():
+    """name -> (params, frames) run through tube.c in TRAcT's OWN loop order (oracle/ref_driver.c `tract`): the "ee" posture
+    held for 68 control periods (29 988 outputs), then one radius stepped to (float)0.4 and held for 68 more."""
+    fr = static_frames(TRACT_SHIM_FRAME, 138)
+    fr[TRACT_STEP_FRAME:, 7 + 6] = float(np.float32(0.4))
+    return {"tract_mode_ee_step": (tract_shim_params(), fr)}
+
+
+# ---------------------------------------------------------------- what a randomized parity run may NOT be asked to match
+def bandpass_unstable(frames, tube_rate):
+    """The frication band-pass (TRMFilters.m:9-29) is y = 2 (alpha (x - x2) + gamma y1 - beta y2) with
+    2 beta = (1 - t) / (1 + t), t = tan(pi BW / SR): its poles leave the unit circle when t <= 0, i.e. from BW = SR / 2 on
+    (SR = the tube's sample rate).  A track that goes there makes the REFERENCE grow exponentially (outputs of 1e13 were
+    seen): rounding differences are amplified without bound and no finite-precision path can match it.  Such a voice is
+    outside the filter's domain and is reported as such, not compared."""
+    fr = np.asarray(frames)
+    return bool(fr.size) and float(fr[:, 6].max()) >= 0.5 * float(tube_rate)
+
+
+ABS_FLOOR = 1e-9     # absolute RMS below which a voice counts as matched whatever its own maximum is (a nearly silent
+                     # voice: the normalisation by its maximum inflates errors of a few 1e-10; speech peaks are ~1e-3 .. 1)
+
+
+def parity_error(pcm, ref_samples, ref_max):
+    """(normalised RMS, absolute RMS) of a voice against the oracle; the bar is nrms <= 1e-5 OR abs <= ABS_FLOOR."""
+    e = np.asarray(pcm, dtype=np.float64) - np.asarray(ref_samples, dtype=np.float64)
+    a = float(np.sqrt(np.mean(e * e))) if e.size else 0.0
+    return (a / ref_max if ref_max > 0 else (0.0 if a == 0.0 else np.inf)), a

@@ -5,6 +5,7 @@ Runs oracle/_ref/tube_ref (Applications/TRAcT/tube.c compiled in place from /roo
 by oracle/Makefile, driven by oracle/ref_driver.c) on every case of tests/cases.golden_cases()
 and freezes what the reference computed: tube-rate doubles, converter output (fp32, as tube.c's
 dataEmpty emits it), numberSamples, maximumSampleValue, FIR taps, derived constants.
+cases.tract_mode_cases() run through the same binary in TRAcT's own loop order (ref_driver.c `tract`).
 Only runs where /root/reference exists; the .npz files are the committed fixtures.
 
     make -C oracle && python tests/golden/make_golden.py
@@ -26,10 +27,11 @@ def main():
     if not O.have_ref():
         sys.exit("oracle/_ref/tube_ref missing: run `make -C oracle` where /root/reference exists")
     h_saved = False
-    for name, (pd, frames) in cases.golden_cases().items():
+    todo = [(n, c, False) for n, c in cases.golden_cases().items()] + [(n, c, True) for n, c in cases.tract_mode_cases().items()]
+    for name, (pd, frames), tract in todo:
         p = O.InputParams.from_dict(pd)
         with tempfile.TemporaryDirectory() as d:
-            r = O.run_ref(p, frames, d)
+            r = O.run_ref(p, frames, d, tract=tract)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
             params_json=np.array(json.dumps(pd)),

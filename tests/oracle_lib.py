@@ -192,8 +192,9 @@ def have_ref():
     return os.path.exists(REF_BIN)
 
 
-def run_ref(params, frames, workdir):
-    """Run oracle/_ref/tube_ref (the reference's own tube.c behind oracle/ref_driver.c)."""
+def run_ref(params, frames, workdir, tract=False):
+    """Run oracle/_ref/tube_ref (the reference's own tube.c behind oracle/ref_driver.c); tract: in TRAcT's own
+    sample-loop order (tube.c:1096-1190: held parameters, x10 taps, x100 gain) instead of Frameworks/Tube's."""
     frames = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 16)
     case = os.path.join(workdir, "case.bin")
     outp = os.path.join(workdir, "out.bin")
@@ -201,7 +202,7 @@ def run_ref(params, frames, workdir):
         f.write(bytes(params))
         f.write(np.uint64(frames.shape[0]).tobytes())
         f.write(frames.tobytes())
-    subprocess.check_call([REF_BIN, case, outp])
+    subprocess.check_call([REF_BIN, case, outp] + (["tract"] if tract else []))
     raw = open(outp, "rb").read()
     o = 0
 
@@ -230,7 +231,7 @@ class Intonation(C.Structure):
     """trm_intonation (include/trm_c_api.h)."""
     _fields_ = [("useMicroIntonation", C.c_int32), ("useMacroIntonation", C.c_int32), ("useSmoothIntonation", C.c_int32),
                 ("useDrift", C.c_int32), ("driftDeviation", C.c_float), ("driftCutoff", C.c_float), ("pitchMean", C.c_double),
-                ("timeQuantization", C.c_uint32), ("startTime_ms", C.c_uint32), ("endTime_ms", C.c_uint32)]
+                ("timeQuantization", C.c_uint32), ("startTime_ms", C.c_uint32), ("endTime_ms", C.c_uint32), ("driftSeed", C.c_float)]
 
 
 def generate_frames(times, values, settings):

@@ -244,3 +244,67 @@ def test_gpu_ragged_batch_events_to_pcm(g):
     assert np.array_equal(st["number_samples"].cpu().numpy(), st2["number_samples"].cpu().numpy())
     assert st["out_alloc"] == st2["out_alloc"] and np.all(np.isfinite(pcm_a[:st["out_alloc"]]))
     assert np.array_equal(pcm_a[:st["out_alloc"]], st2["out"].cpu().numpy()[:st2["out_alloc"]])
+
+
+def test_drift_seed_carries_over_between_utterances():
+    """The reference keeps ONE drift generator per EventList; only -init sets its seed, -configure... resets the filter
+    memory but "seed is not changed" (MMDriftGenerator.m:27-58, EventList.m:105-106, 903): the second utterance of a
+    list continues the noise sequence.  trm_intonation.driftSeed + trm_drift_seed_after() give a caller that: the
+    second utterance generated with the carried seed equals the numpy restatement continued across both."""
+    import gnuspeech_amd as g
+    f32 = np.float32
+    L = g.lib()                                            # host-side bookkeeping: loads without a GPU
+    times = np.array([0, 400], dtype=np.uint32)
+    vals = np.zeros((2, NV))
+    s1 = settings(micro=0, macro=0, drift=1, dev=1.5, cutoff=4.0, pitch=0.0)
+    a = O.generate_frames(times, vals, s1)
+    seed_after = L.trm_drift_seed_after(0.0, len(a))
+    s2 = settings(micro=0, macro=0, drift=1, dev=1.5, cutoff=4.0, pitch=0.0)
+    s2.driftSeed = seed_after
+    b = O.generate_frames(times, vals, s2)
+    # numpy: one generator, two utterances (the filter memory is cleared by -configure..., the seed is not)
+    seed = f32(0.7892347)
+    a0 = f32((np.float64(f32(4.0)) * 2.0) / np.float64(f32(250.0)))
+    b1 = f32(1.0 - np.float64(a0))
+    dev2, off = f32(np.float64(f32(1.5)) * 2.0), f32(1.5)
+    both = []
+    for utt in range(2):
+        prev, want = f32(0.0), []
+        for _ in range(len(a)):
+            temp = f32(seed * f32(377.0))
+            seed = f32(temp - f32(np.int32(temp)))
+            temp = f32(f32(seed * dev2) - off)
+            prev = f32(f32(a0 * temp) + f32(b1 * prev))
+            want.append(prev)
+        both.append(np.array(want, dtype=np.float32))
+        if utt == 0:
+            assert f32(seed_after) == seed
+    assert np.array_equal(a[:, 0], both[0]) and np.array_equal(b[:, 0], both[1])
+    assert not np.array_equal(a[:, 0], b[:, 0])
+
+
+@pytest.mark.gpu
+def test_gpu_drift_seed_carries_over(g):
+    """The device generator with a carried seed == the oracle with the same seed, bit for bit; gnuspeech_amd.EventList
+    carries it by itself like the reference's EventList (second utterance of the same list)."""
+    import cases
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params()))
+    rng = np.random.default_rng(23)
+    times, vals = random_events(rng, 25, smooth=False)
+    el = g.EventList(pitch_mean=-9.5)
+    for t, v in zip(times, vals):
+        e = g.Event(t)
+        e.values[:] = v
+        el.events.append(e)
+    el.intonation.shouldUseSmoothIntonation = False
+    el.intonation.driftDeviation, el.intonation.driftCutoff = 0.8, 3.0
+    first = el.generateOutputInTimeRange(b)
+    assert el.driftSeed != 0.0
+    second = el.generateOutputInTimeRange(b)
+    s = settings(1, 1, 0, 1, dev=0.8, cutoff=3.0, pitch=-9.5)
+    want1 = O.generate_frames(times, vals, s)
+    s.driftSeed = g.lib().trm_drift_seed_after(0.0, len(want1))
+    want2 = O.generate_frames(times, vals, s)
+    assert np.array_equal(first.view(np.uint32), want1.view(np.uint32))
+    assert np.array_equal(second.view(np.uint32), want2.view(np.uint32))
+    assert not np.array_equal(first, second)

@@ -594,11 +594,14 @@ def test_concurrent_handles_from_threads(g):
             assert all(np.array_equal(a, b) for a, b in zip(res, seq[k][0])), k
 
 
-def test_hip_graph_capture_and_replay(g, form):
+@pytest.mark.parametrize("rate", [44100.0, 16000.0])
+def test_hip_graph_capture_and_replay(g, form, rate):
     """With launch timing off the device entry is pure stream work: captured once into a HIP graph (torch.cuda.graph) and
-    replayed, it reproduces the direct launch bit for bit, also after the input frames changed in place."""
+    replayed, it reproduces the direct launch bit for bit, also after the input frames changed in place.  16 kHz: the
+    down-sampling branch (tube kernel + conversion kernel; its row offsets are uploaded when the batch shape changes, not
+    per launch, so the entry stays capturable)."""
     import torch
-    pd = cases.monet_default_params(44100.0)
+    pd = cases.monet_default_params(rate)
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
     fr = cases.config3_frames(40, nframes=26)
     st = b.prepare_device(fr)
@@ -655,3 +658,63 @@ def test_full_size_properties(g, form):
     for v in (0, 777, 4094):
         o = O.synthesize(op, fr[v].astype(np.float32).astype(np.float64))
         assert nrms(out[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL
+
+
+
+def test_full_size_ragged_batch_config3(g):
+    """BASELINE configs[3] at FULL size: 1024 ragged utterances (150 - 1500 frames, seed 20250119) through the host-buffer
+    entry, in the caller's (unsorted) order -- the library orders the voices by length internally.  Size-independent
+    properties: every voice's exact sample count, finite PCM, the reported maximum is the maximum, identical utterances
+    give identical bits wherever they sit; and a sample of voices (the shortest, the longest, some in between) against the
+    oracle at the one tolerance."""
+    pd = cases.monet_default_params(44100.0)
+    utt = cases.config4_frames(1024)
+    utt[1000] = utt[3].copy()                                   # the same utterance at two places of the batch
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    pcm, ns, mx = b.synthesize(utt)
+    lens = np.array([len(u) for u in utt])
+    assert lens.min() >= 150 and lens.max() <= 1500 and len(set(lens.tolist())) > 500
+    want = np.array([b.samples_for_frames(int(n)) for n in lens])
+    assert np.array_equal(ns, want)
+    for v in range(1024):
+        assert np.all(np.isfinite(pcm[v])) and pcm[v].size == want[v]
+        assert float(mx[v]) == float(np.abs(pcm[v]).max())
+    assert np.array_equal(pcm[3], pcm[1000])
+    op = O.InputParams.from_dict(pd)
+    order = np.argsort(lens)
+    for v in (int(order[0]), int(order[-1]), int(order[511]), 3, 777):
+        o = O.synthesize(op, np.asarray(utt[v], dtype=np.float32).astype(np.float64))
+        assert o["numberSamples"] == int(ns[v])
+        assert nrms(pcm[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL, v
+
+
+def test_host_entry_leaves_gaps_between_voices_alone(g, form):
+    """include/trm_c_api.h promises writes at out + out_offset[v] only: with padded offsets, what lies between the voices
+    (and in front of the first one) in the caller's buffer is not touched, fp32 and int16."""
+    import ctypes as C
+    pd = cases.monet_default_params(44100.0)
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    voices = [np.asarray(v, dtype=np.float32) for v in cases.config3_frames(5, nframes=12)]
+    voices[2] = voices[2][:7]
+    ref, ns_ref, _ = b.synthesize(voices)
+    nfr = np.array([len(v) for v in voices], dtype=np.uint32)
+    foff = np.concatenate([[0], np.cumsum(nfr[:-1])]).astype(np.uint64)
+    frames = np.ascontiguousarray(np.concatenate(voices), dtype=np.float32)
+    nout = np.array([b.samples_for_frames(int(n)) for n in nfr], dtype=np.uint64)
+    pad = 1000
+    ooff = (np.concatenate([[0], np.cumsum(nout[:-1] + pad)]) + pad).astype(np.uint64)
+    total = int(ooff[-1] + nout[-1] + pad)
+    L = g.lib()
+    for dtype, entry, extra in ((np.float32, L.trm_batch_synthesize_host, ()), (np.int16, L.trm_batch_synthesize_host_int16, (0,))):
+        out = np.full(total, 12345, dtype=dtype)
+        ns = np.zeros(5, dtype=np.uint32)
+        mx = np.zeros(5, dtype=np.float32)
+        rc = entry(b._h, 5, frames.ctypes.data, foff.ctypes.data, nfr.ctypes.data, out.ctypes.data, ooff.ctypes.data,
+                   ns.ctypes.data, mx.ctypes.data, *extra)
+        assert rc == 0 and np.array_equal(ns, ns_ref)
+        mask = np.ones(total, dtype=bool)
+        for v in range(5):
+            mask[int(ooff[v]):int(ooff[v] + nout[v])] = False
+            if dtype is np.float32:
+                assert np.array_equal(out[int(ooff[v]):int(ooff[v] + nout[v])], ref[v])
+        assert np.all(out[mask] == 12345)

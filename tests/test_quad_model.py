@@ -56,3 +56,15 @@ def test_both_formulations_against_oracle(emul, name):
         e = (out[:n.value].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
         assert float(np.sqrt(np.mean(e * e))) <= 1e-5
         assert abs(m.value - o["maximumSampleValue"]) / o["maximumSampleValue"] < 2e-4
+
+
+def test_product_fir_table_equals_reference_taps(emul):
+    """The product carries the oscillator FIR as a constant table (TRMFIRFilter.h:7-9 fixes the design's inputs); it must
+    be what the REFERENCE binary computed (firCoef of every fixture), to the last bit of the double."""
+    half = np.zeros(25)
+    emul.trm_emul_fir_half.argtypes = [C.POINTER(C.c_double)]
+    emul.trm_emul_fir_half(half.ctypes.data_as(C.POINTER(C.c_double)))
+    for name in golden_io.CASE_NAMES:
+        ref = golden_io.load(name)["firCoef"]
+        assert len(ref) == 49
+        assert np.array_equal(half, ref[:25]) and np.array_equal(half[:24], ref[:24:-1])

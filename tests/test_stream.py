@@ -156,3 +156,24 @@ def test_stream_matches_oracle(g, rate, seed):
         e = nrms(got[v], o["samples"], o["maximumSampleValue"])
         assert e <= 1e-5, "voice %d: normalised RMS %.3e, chunks %s" % (v, e, chunks)
         assert abs(float(got_max[v]) - o["maximumSampleValue"]) / o["maximumSampleValue"] < 2e-4
+
+
+def test_stream_against_the_reference_in_tract_order(g):
+    """The one-voice stream (what TRAcT's real-time loop maps onto) pushed one control period at a time, against the
+    REFERENCE's tube.c stepped in TRAcT's own loop order (tests/golden/tract_mode_ee_step, oracle/ref_driver.c `tract`):
+    x100 applied after the converter here, before it there (linear).  <= 1e-5 on the held posture and on the steady
+    state after the radius change; during the control period of the change the stream glides where tube.c steps
+    (documented divergence: Frameworks/Tube's interpolation, TRMTubeModel.m:611-688) and the test pins that as well."""
+    import golden_io
+    gold = golden_io.load("tract_mode_ee_step")
+    fr = gold["frames"].astype(np.float32)
+    want, mx = gold["samples_f32"].astype(np.float64), gold["maximumSampleValue"]
+    s = g.TRMStream(g.TRMInputParameters.from_dict(gold["params_dict"]), nvoices=1)
+    parts = [s.push(fr[i:i + 1])[0][0] for i in range(len(fr))]
+    parts.append(s.finish()[0][0])
+    got = np.concatenate(parts).astype(np.float64) * 100.0
+    assert got.size == gold["numberSamples"]
+    step_at = int(cases.TRACT_STEP_FRAME - 1) * 441            # first output of the stepped control period (29 988)
+    assert nrms(got[:step_at - 100], want[:step_at - 100], mx) <= 1e-5
+    assert nrms(got[step_at + 20000:], want[step_at + 20000:], mx) <= 1e-5
+    assert nrms(got[step_at:step_at + 2000], want[step_at:step_at + 2000], mx) > 1e-3
