@@ -321,7 +321,7 @@ TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, 
 
 // ================================================================ stage 2: coefficients
 struct CoefTrack {
-    double fricPos0, fricPosDelta;
+    float fricPos0, fricPosDelta;
     // fp32 base + delta: fricVol, fricCF, fricBW, r1..r8, velum
     float base[12], delta[12];
 };
@@ -340,8 +340,8 @@ struct Coefs {
 // frame columns: 3 fricVol, 4 fricPos, 5 fricCF, 6 fricBW, 7..14 radii, 15 velum
 TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, const float *cur)
 {
-    T.fricPos0 = (double)prev[4];
-    T.fricPosDelta = ((double)cur[4] - T.fricPos0) / (double)C.controlPeriod;
+    T.fricPos0 = prev[4];
+    T.fricPosDelta = (cur[4] - prev[4]) * C.invControlPeriod;
     const int col[12] = {3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
     for (int i = 0; i < 12; i++) {
         T.base[i] = prev[col[i]];
@@ -384,17 +384,17 @@ TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j
     float fricDb = fma_f(fj, T.delta[0], T.base[0]);
     float fricCF = fma_f(fj, T.delta[1], T.base[1]);
     float fricBW = fma_f(fj, T.delta[2], T.base[2]);
-    // frication taps (:748-773)
+    // frication taps (:748-773).  The reference splits the position into (int) and fraction and gives the two taps
+    // around it (1 - frac) amp and frac amp: the values of ONE continuous function, tap[i] = amp max(0, 1 - |pos - i|)
+    // (linear interpolation between the taps; position 7.x: the second tap would be FC9, which does not exist, :761).
+    // Evaluated that way there is no discontinuity for fp32 to miss (the (int) cast disappears), no fp64 and no
+    // select chain: three plain operations per tap.  Positions below 0 are outside the tract (the reference's split
+    // is meaningless there as well).
     float fricAmp = amplitude_f(fricDb);
-    const double fricPos = T.fricPos0 + (double)j * T.fricPosDelta;   // (:676-688), fp64: feeds (int)
-    int ip = (int)fricPos;
-    float comp = (float)(fricPos - (double)ip);
-    float tapA = (1.0f - comp) * fricAmp;       // tap[ip]
-    float tapB = comp * fricAmp;                // tap[ip+1] when ip+1 < 8
-    K.tap[0] = ip == 0 ? tapA : 0.0f;
-    for (int i = 1; i < 8; i++) {
-        float t = i == ip ? tapA : 0.0f;
-        K.tap[i] = i - 1 == ip ? tapB : t;
+    const float fricPos = fma_f(fj, T.fricPosDelta, T.fricPos0);                 // (:676-688)
+    for (int i = 0; i < 8; i++) {
+        const float dist = fabsf(fricPos - (float)i);
+        K.tap[i] = fmaxf(fma_f(-fricAmp, dist, fricAmp), 0.0f);
     }
 
     // band-pass coefficients (TRMFilters.m:9-17): tan(pi*BW/SR), cos(2*pi*CF/SR)

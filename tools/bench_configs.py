@@ -32,10 +32,15 @@ def timed_device(frames, label, reps=3):
 fr = cases.config3_frames(4096, nframes=251)
 timed_device(fr, "configs[2] 4096 time-varying tubes x 1 s, device-resident")
 utt = cases.config4_frames(1024)
+caller_order = list(utt)
 utt.sort(key=len)
 timed_device(utt, "configs[3] 1024 ragged utterances (%.1f - %.1f s, %.0f s of speech), device-resident" % (len(utt[0]) / 250, len(utt[-1]) / 250, sum(len(u) - 1 for u in utt) / 250))
-b.synthesize(utt[:8])
-t0 = time.perf_counter()
-pcm, ns, mx = b.synthesize(utt)
-dt = time.perf_counter() - t0
-print("configs[3] same batch through the host-buffer entry (H2D + kernel + D2H): %.1f ms, %.3e samples/s" % (dt * 1e3, int(ns.sum()) / dt))
+# the host-buffer entry takes the batch in the CALLER's order (random lengths): the library orders the voices by length itself
+for label, fn, kw in (("fresh fp32 output buffer", b.synthesize, {}), ("kept fp32 output buffer", b.synthesize, {"reuse_output": True}),
+                      ("kept int16 output buffer (scaled on the device)", b.synthesize_int16, {"reuse_output": True})):
+    fn(caller_order, **kw)
+    t0 = time.perf_counter()
+    pcm, ns, mx = fn(caller_order, **kw)
+    dt = time.perf_counter() - t0
+    print("configs[3] same batch, caller order, through the host-buffer entry (packing + H2D + kernel + D2H), %s: %.1f ms, %.3e samples/s" % (label, dt * 1e3, int(ns.sum()) / dt))
+    pcm = None
