@@ -146,3 +146,26 @@ def test_pulse_shape_beyond_the_table_is_refused():
         O.synthesize(O.InputParams.from_dict(pd), np.zeros((3, 16)))
     pd.update(tp=40.0, tnMin=16.0, tnMax=32.0)                      # the Monet default shape is fine
     shard.derive(g.TRMInputParameters.from_dict(pd))
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
+    """bench.py --gpus N must run N ranks or say so: with WORLD_SIZE set to something else it exits with a message instead of
+    reporting n_gpus from the environment (--gpus was parsed and never used)."""
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_traffic_file_is_stamped_with_the_kernel_sources():
+    """profiles/traffic_r02.json (what bench.py quotes roofline.traffic from) carries the hash of the kernel sources it was
+    measured on; bench.kernel_source_hash() is what bench.py compares it with (a stale file is refused, not quoted)."""
+    import json, sys
+    sys.path.insert(0, ROOT)
+    import bench
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
+    assert set(("kernel_source_sha16", "workload", "traffic_bytes_per_launch", "SQ_INSTS_VALU", "issue_cycles_per_valu")) <= set(tj)
+    assert tj["workload"]["kernel_form"] in ("quad", "wide")
