@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             Coefs K;
             K.td[0] = k0.x; K.td[1] = k0.y; K.td[2] = k0.z; K.td[3] = k0.w;
             K.td[4] = k1.x; K.td[5] = k1.y; K.td[6] = k1.z; K.onePlusK8 = k1.w;
-            K.k8 = K.onePlusK8 - 1.0f;                   // C8 (near -1 when the mouth closes: no cancellation here)
+            K.k8a = (K.onePlusK8 - 1.0f) * C.mA10;       // C8 a10 (C8 is near -1 when the mouth closes: no cancellation here)
             K.alphaU = k2.x; K.ntd1 = k2.y; K.bpBeta = k2.z; K.bpGamma = k2.w;
             K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);    // the three alphas sum to 2 (TRMTubeModel.m:733-736)
             K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;        // TRMFilters.m:16

@@ -97,6 +97,7 @@ struct Const {
     float nasalTd[4];           // (1 + NC2..NC5) times damping, formed in double without cancellation: the junctions'
                                 // working form (tube_step)
     float onePlusNK6;           // 1 + NC6, formed in double                 (:849)
+    float nasalK6a;             // NC6 times the nose reflection filter's a10 (:848, TRMFilters.m:47-52)
     float noseR1sq;             // noseRadius[1]^2, for NC1                  (:741)
     float apScaleSq;            // apScale^2, for C8                         (:724)
     // mouth / nose reflection+radiation pairs (TRMFilters.m:34-45): a20 = coeff, a21 = b21 = b11 =
@@ -327,7 +328,7 @@ struct CoefTrack {
 };
 
 struct Coefs {
-    float k8;                   // C8                                       (:723-725)
+    float k8a;                  // C8 times the mouth reflection filter's a10: what the end filter multiplies by (:723-725, :820)
     float td[7], ntd1;          // (1 + C1..C7), (1 + NC1) times damping, formed without cancellation: what the
                                 // junctions multiply by (tube_step)         (:712-722, :738-743)
     float onePlusK8;            // 1 + C8 without cancellation              (:835)
@@ -369,7 +370,7 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
     const float d2 = C.damping + C.damping;
     for (int i = 0; i < 7; i++) K.td[i] = r2[i] * (d2 * rcp_f(r2[i] + r2[i + 1]));
     float rk8 = rcp_f(r2[7] + C.apScaleSq);
-    K.k8 = (r2[7] - C.apScaleSq) * rk8;
+    K.k8a = ((r2[7] - C.apScaleSq) * rk8) * C.mA10;
     K.onePlusK8 = (r2[7] + r2[7]) * rk8;         // 1 + C8 without the cancellation of a nearly closed mouth
     float v2 = velum * velum;
     float jsum = 2.0f * rcp_f(r2[3] + r2[3] + v2);
@@ -516,7 +517,7 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
     }
     wg_t out;
     {   // mouth: reflection y = a10*x - b11*y1, radiation y = a20*x + a21*x1 - b21*y1 (TRMFilters.m:47-60)
-        wg_t refl = C.mA10 * (K.k8 * o.oT[9]) + C.mCoeff * L.mReflY;
+        wg_t refl = fma_f((wg_t)K.k8a, o.oT[9], C.mCoeff * L.mReflY);
         L.mReflY = refl;
         nw.oB[9] = d * refl;
         wg_t rin = K.onePlusK8 * o.oT[9];
@@ -527,7 +528,7 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C
     {
         float tt[5] = {K.ntd1, C.nasalTd[0], C.nasalTd[1], C.nasalTd[2], C.nasalTd[3]};
         for (int i = 0; i < 5; i++) junction(tt[i], o.nT[i], o.nB[i + 1], nw.nT[i + 1], nw.nB[i]);
-        wg_t refl = C.nA10 * (C.nasalK[4] * o.nT[5]) + C.nCoeff * L.nReflY;
+        wg_t refl = fma_f((wg_t)C.nasalK6a, o.nT[5], C.nCoeff * L.nReflY);
         L.nReflY = refl;
         nw.nB[5] = d * refl;
         wg_t rin = C.onePlusNK6 * o.nT[5];

@@ -51,6 +51,8 @@ template <int K, int MASK>
 __device__ __forceinline__ float q_take(float old, float src)
 {
     constexpr int ctrl = K == 0 ? 0xE4 /* quad_perm:[0,1,2,3] */ : 0x120 + 4 * K /* row_ror:4K */;
+    if (MASK == kPartAll)       // every part takes: no lane keeps `old`, so the destination need not start as a copy of it
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), ctrl, 0xF, 0xF, false));
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), ctrl, 0xF, MASK, false));
 }
@@ -106,7 +108,7 @@ TRM_HD void pack_part_records(const Coefs &K, const Const &C, PartRecord R[4])
 
 // Per-sample coefficients every part reads: the band-pass DOUBLED (y = 2 (alpha (x - x2) + gamma y1 - beta y2),
 // TRMFilters.m:19-29, with the factor folded in: exact in binary floating point) and the end filters'
-// {C8, NC6}, {1 + C8, 1 + NC6} (:820-836, :848-852).
+// {C8 a10, NC6 a10} (the reflection filters' input gains), {1 + C8, 1 + NC6} (:820-836, :848-852).
 struct SharedRecord {
     float bpA2, bpB2, bpG2, pad_;
     float endK[2], endOnePlus[2];
@@ -118,8 +120,8 @@ TRM_HD void pack_shared_bp(const Coefs &K, SharedRecord &R)                     
 }
 TRM_HD void pack_shared_end(const Coefs &K, const Const &C, SharedRecord &R)    // coef_sample_area's fields
 {
-    R.endK[0] = K.k8;
-    R.endK[1] = C.nasalK[4];
+    R.endK[0] = K.k8a;
+    R.endK[1] = C.nasalK6a;
     R.endOnePlus[0] = K.onePlusK8;
     R.endOnePlus[1] = C.onePlusNK6;
 }
@@ -237,8 +239,8 @@ TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F ty, typename P
         S.jN = (jp - x3) * d;
     }
     // ---- mouth and nose ends: reflection + radiation (:820-836, :848-852, TRMFilters.m:47-60), two-wide
-    const P cf = pk_make(F(C.mCoeff), F(C.nCoeff)), a10 = pk_make(F(C.mA10), F(C.nA10));
-    P refl = a10 * (endK * ei) + cf * S.reflY;
+    const P cf = pk_make(F(C.mCoeff), F(C.nCoeff));
+    P refl = pk_fma(endK, ei, cf * S.reflY);
     S.reflY = refl;
     S.eB = dd * refl;
     P rin = endOnePlus * ei;

@@ -159,6 +159,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     c.damping = (float)(1.0 - p.lossFactor / 100.0);                     // :216
     c.breath = (float)(p.breathiness / 100.0);                           // :210
     c.crossmixFactor = (float)(1.0 / amplitude(p.mixOffset));            // :213
+    double nk6 = 0.0;
     for (int i = 1; i < 5; i++) {                                        // :695-699
         double a2 = p.noseRadius[i] * p.noseRadius[i], b2 = p.noseRadius[i + 1] * p.noseRadius[i + 1];
         c.nasalK[i - 1] = (float)((a2 - b2) / (a2 + b2));
@@ -168,6 +169,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
         double a2 = p.noseRadius[5] * p.noseRadius[5], b2 = p.apScale * p.apScale;   // :703-705
         c.nasalK[4] = (float)((a2 - b2) / (a2 + b2));
         c.onePlusNK6 = (float)(1.0 + (a2 - b2) / (a2 + b2));
+        nk6 = (a2 - b2) / (a2 + b2);
     }
     c.noseR1sq = (float)(p.noseRadius[1] * p.noseRadius[1]);
     c.apScaleSq = (float)(p.apScale * p.apScale);
@@ -176,6 +178,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
         c.mCoeff = (float)coeff; c.mA10 = (float)(1.0 - fabs(-coeff));
         coeff = (nyquist - p.noseCoef) / nyquist;                        // :225
         c.nCoeff = (float)coeff; c.nA10 = (float)(1.0 - fabs(-coeff));
+        c.nasalK6a = (float)(nk6 * (1.0 - fabs(-coeff)));                // NC6 a10: the nose end's reflection gain (:848)
     }
     {
         double ta0 = (p.throatCutoff * 2.0) / d.sampleRate;              // :238

@@ -216,7 +216,7 @@ extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, uns
         Coefs K;
         for (int i = 0; i < 7; i++) K.td[i] = (1.0f + rnd() * 0.9f) * C.damping;
         K.onePlusK8 = 1.0f + rnd() * 0.9f;
-        K.k8 = K.onePlusK8 - 1.0f;
+        K.k8a = (K.onePlusK8 - 1.0f) * C.mA10;
         K.alphaU = rnd() * 0.5f + 0.5f;
         K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);
         K.ntd1 = (1.0f + rnd() * 0.9f) * C.damping;
