@@ -66,13 +66,19 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 #ifndef TRM_STAMP_LONG
 #define TRM_STAMP_LONG 1600      /* cycles: a step's work above this counts as a long step */
 #endif
-#define STAMP_DECL unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0, st_long = 0, st_excess = 0, st_max = 0; const unsigned long long st_born = __builtin_amdgcn_s_memrealtime();
+/* per-step trace of workgroup 0 (tools/stage_profile.py --trace): work cycles of role r at step i in stamps[400000 + r * 4096 + i] */
+#ifdef TRM_STAMP_TRACE
+#define STAMP_TRACE if (blockIdx.x == 0 && lane == 0 && A.stamps && st_n < 4096) A.stamps[400000 + role * 4096 + st_n] = st_t1 - st_t0; st_n++;
+#else
+#define STAMP_TRACE
+#endif
+#define STAMP_DECL unsigned st_n = 0; (void)st_n; unsigned long long st_work = 0, st_wait = 0, st_t0 = 0, st_t1 = 0, st_long = 0, st_excess = 0, st_max = 0; const unsigned long long st_born = __builtin_amdgcn_s_memrealtime();
 #define SUB_DECL unsigned long long sub_t = 0, sub_acc[6] = {0, 0, 0, 0, 0, 0};
 #define SUB_START sub_t = __builtin_readcyclecounter();
 #define SUB_LAP(i_) { unsigned long long n_ = __builtin_readcyclecounter(); sub_acc[i_] += n_ - sub_t; sub_t = n_; }
 #define SUB_STORE(role_) if (lane == 0 && A.stamps) for (int i_ = 0; i_ < 6; i_++) A.stamps[(blockIdx.x * kStampRoles + (role_)) * 8 + 2 + i_] = sub_acc[i_];
 #define STAMP_BEGIN st_t0 = __builtin_readcyclecounter();
-#define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0; if (st_t1 - st_t0 > TRM_STAMP_LONG) { st_long++; st_excess += st_t1 - st_t0 - TRM_STAMP_LONG; } if (st_t1 - st_t0 > st_max) st_max = st_t1 - st_t0;
+#define STAMP_MID st_t1 = __builtin_readcyclecounter(); st_work += st_t1 - st_t0; STAMP_TRACE if (st_t1 - st_t0 > TRM_STAMP_LONG) { st_long++; st_excess += st_t1 - st_t0 - TRM_STAMP_LONG; } if (st_t1 - st_t0 > st_max) st_max = st_t1 - st_t0;
 #define STAMP_END st_wait += __builtin_readcyclecounter() - st_t1;
 #define STAMP_STORE(role_)                                                          \
     if (lane == 0 && A.stamps) {                                                    \
