@@ -30,11 +30,17 @@ def g():
     return gnuspeech_amd
 
 
-@pytest.fixture(params=["wide", "quad"])
+@pytest.fixture(params=["wide", "quad", "quad1"])
 def form(request, monkeypatch):
-    """Both kernel forms (include/trm_c_api.h: one voice per lane / four lanes per voice) must meet the
-    same bar; TRM_TUBE_KERNEL steers every launch that is left on TRM_KERNEL_AUTO."""
-    monkeypatch.setenv("TRM_TUBE_KERNEL", request.param)
+    """Every kernel form must meet the same bar (include/trm_c_api.h): one voice per lane, four lanes per voice, and the
+    four-lane form's second instance ("quad1": one block per pipeline step, the one that lets two workgroups share a CU and
+    that batches of more than 16 voices x CUs run; TRM_QUAD_CUS=1 makes every batch take it).  TRM_TUBE_KERNEL steers every
+    launch that is left on TRM_KERNEL_AUTO; both variables are read when a batch object is created."""
+    monkeypatch.setenv("TRM_TUBE_KERNEL", "quad" if request.param == "quad1" else request.param)
+    if request.param == "quad1":
+        monkeypatch.setenv("TRM_QUAD_CUS", "1")
+    else:
+        monkeypatch.delenv("TRM_QUAD_CUS", raising=False)
     return request.param
 
 
@@ -718,3 +724,31 @@ def test_host_entry_leaves_gaps_between_voices_alone(g, form):
             if dtype is np.float32:
                 assert np.array_equal(out[int(ooff[v]):int(ooff[v] + nout[v])], ref[v])
         assert np.all(out[mask] == 12345)
+
+
+
+def test_full_size_configs4_per_gpu_batch(g):
+    """BASELINE configs[4]'s per-GPU shard at FULL size: 8192 config-3 voices (time-varying gnuspeech.input tracks) x 1 s, the
+    batch that runs as two co-resident workgroups per CU.  Size-independent properties (exact counts, finite, the reported
+    maximum is the maximum, identical tracks give identical bits wherever they sit) and a sample of voices against the oracle."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    fr = cases.config3_frames(8192, nframes=251)
+    fr[8191] = fr[5]
+    fr[4100] = fr[5]
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    st = b.prepare_device(fr)
+    b.synthesize_device(st)
+    torch.cuda.synchronize()
+    assert b.last_kernel == "quad"
+    ns = st["number_samples"].cpu().numpy()
+    assert np.all(ns == 44159)
+    out = st["out"].cpu().numpy().reshape(8192, st["out_alloc"] // 8192)[:, :44159]
+    assert np.all(np.isfinite(out))
+    assert np.array_equal(out[5], out[8191]) and np.array_equal(out[5], out[4100])
+    mx = st["max_sample"].cpu().numpy()
+    assert np.array_equal(mx, np.abs(out).max(axis=1))
+    op = O.InputParams.from_dict(pd)
+    for v in (0, 4097, 8190):
+        o = O.synthesize(op, fr[v].astype(np.float32).astype(np.float64))
+        assert nrms(out[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL
