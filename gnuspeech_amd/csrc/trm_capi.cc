@@ -190,7 +190,9 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     // 9.0 ms) while the one-voice-per-lane form takes 7.1 ms for anything up to 16384 (profiles/sweep_forms_r01.txt).
     b->wideThreshold = 2u * 16u * (uint32_t)prop.multiProcessorCount + 1u;
     b->cus = prop.multiProcessorCount;
-    if (const char *e = getenv("TRM_QUAD_CUS")) b->cus = atoi(e);     // (experiments: 0 = always two blocks per step, 1 = always one)
+    // (tests and experiments: 0 = the four-lane form always with two blocks per pipeline step, 1 = always with one --
+    // tests/test_gpu_parity.py runs every parity test in that instance too)
+    if (const char *e = getenv("TRM_QUAD_CUS")) b->cus = atoi(e);
     if (const char *e = getenv("TRM_TUBE_KERNEL")) b->envKernel = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : TRM_KERNEL_AUTO;
     b->envDownGeneric = getenv("TRM_DOWNSAMPLE_GENERIC") != nullptr;
     hipError_t e;

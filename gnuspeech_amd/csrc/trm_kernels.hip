@@ -19,8 +19,13 @@
 #include "trm_kernels.h"
 #include "trm_lane.h"
 
+// Timing experiments live behind ONE switch (-DTRM_EXPERIMENTS, tools/build_variant.sh); the product build defines none of them.
+#ifndef TRM_EXPERIMENTS
+#undef TRM_ABL
+#undef TRM_ROLE_PERM
+#endif
 #ifndef TRM_ABL
-#define TRM_ABL 0    // diagnostic ablations of the convert stage (tools/stage_profile.py); 0 in the product
+#define TRM_ABL 0    // diagnostic ablations of the convert stage; 0 in the product
 #endif
 
 namespace trm {
