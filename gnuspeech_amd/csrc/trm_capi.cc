@@ -102,6 +102,7 @@ struct trm_batch {
     int lastKernel = TRM_KERNEL_AUTO;    // what the last launch ran
     int cus = 0;                         // compute units of the device (set at create)
     int envKernel = TRM_KERNEL_AUTO;     // TRM_TUBE_KERNEL, read once at create (steers launches left on AUTO; tests)
+    bool oct = false;                    // TRM_QUAD_OCT (tests / experiments for now): small batches of TRM_KERNEL_QUAD run trm_oct.hip's kernel
     bool envDownGeneric = false;         // TRM_DOWNSAMPLE_GENERIC, read once at create (tests: the generic down-sampling kernel)
     size_t tubeOffVoices = 0;            // dTubeOff holds pitch * v for v < tubeOffVoices ...
     uint64_t tubeOffPitch = 0;           // ... at this row pitch (down-sampling batches: rebuilt only when either changes)
@@ -194,6 +195,7 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     // tests/test_gpu_parity.py runs every parity test in that instance too)
     if (const char *e = getenv("TRM_QUAD_CUS")) b->cus = atoi(e);
     if (const char *e = getenv("TRM_TUBE_KERNEL")) b->envKernel = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : TRM_KERNEL_AUTO;
+    if (const char *e = getenv("TRM_QUAD_OCT")) b->oct = atoi(e) != 0;
     b->envDownGeneric = getenv("TRM_DOWNSAMPLE_GENERIC") != nullptr;
     hipError_t e;
 #define B_TRY(expr)                                                              \
@@ -475,7 +477,12 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // one-voice-per-lane form runs, whatever was asked for.
     if (which == TRM_KERNEL_QUAD && quad_ratio_too_high(b->c)) which = TRM_KERNEL_WIDE;
     b->lastKernel = which;
-    if (which == TRM_KERNEL_QUAD)
+    // Batches of at most two 8-voice workgroups per CU: the instance with eight lanes per voice (trm_oct.hip; its
+    // feed-forward waves step 8 samples at a time, so a control period must hold at least that many)
+    const bool oct = b->oct && b->c.controlPeriod >= 8 && b->cus > 0 && (nvoices + 7) / 8 <= 2 * (size_t)b->cus;
+    if (which == TRM_KERNEL_QUAD && oct)
+        HIP_TRY(trm::launch_tube_oct(b->c, a, stream));
+    else if (which == TRM_KERNEL_QUAD)
         HIP_TRY(trm::launch_tube_quad(b->c, a, stream, b->cus));
     else
         HIP_TRY(trm::launch_tube(b->c, a, stream));

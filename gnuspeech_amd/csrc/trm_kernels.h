@@ -64,6 +64,9 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
 constexpr int kStreamFloats = 192;   // oscillator position, filter memories, 32 samples of FIR / converter history, 4 x 20 tube values
 // `cus` = the device's compute units: more workgroups than that run the instance that fits two per CU
 hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t stream, int cus);
+// eight lanes per voice, 8 voices per workgroup (trm_oct.hip): one-shot batches of at most two workgroups per CU
+hipError_t launch_tube_oct(const Const &c, const TubeArgs &a, hipStream_t stream);
+int tube_oct_kernel_blocks_per_cu();
 int tube_quad_kernel_blocks_per_cu(int sub);     // sub = blocks per pipeline step of the instance asked about (1 or 2)
 // Down-sampling converter (TRMSampleRateConverter.m:234-297) over tube-rate samples in HBM.
 struct DownArgs {

@@ -276,8 +276,10 @@ struct OscSlotTrack {
     float aspBase, aspDelta;
 };
 
-// `j` = the lane's position in the new control period, 0 <= j < kSlots.
-TRM_HD void osc_slot_setup(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j)
+// `j` = the lane's position in the new control period, 0 <= j < 2^kLog2Slots; the lane's tracks then advance
+// 2^kLog2Slots samples at a time (four: trm_quad.hip; eight: trm_oct.hip).
+template <int kLog2Slots>
+TRM_HD void osc_slot_setup_pow2(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j)
 {
     const double kLog2_10_over_20 = 0.16609640474436813;
     double p0 = (double)prev[0], dp = ((double)cur[0] - p0) * C.invControlPeriodD;
@@ -286,17 +288,26 @@ TRM_HD void osc_slot_setup(OscSlotTrack &T, const Const &C, const float *prev, c
     double v0 = (double)prev[1], dv = ((double)cur[1] - v0) / (double)C.controlPeriod;
     double ax = exp2_d((v0 - 60.0) * kLog2_10_over_20);
     double q = exp2_d(dv * kLog2_10_over_20);
-    double r2 = r * r, q2 = q * q;
-    double rj = ((j & 1) ? r : 1.0) * ((j & 2) ? r2 : 1.0);
-    double qj = ((j & 1) ? q : 1.0) * ((j & 2) ? q2 : 1.0);
+    // r^j, q^j by the bits of j; r^(2^kLog2Slots) is what is left in r
+    double rj = 1.0, qj = 1.0;
+    for (int b = 0; b < kLog2Slots; b++) {
+        rj *= ((j >> b) & 1) ? r : 1.0;
+        qj *= ((j >> b) & 1) ? q : 1.0;
+        r *= r;
+        q *= q;
+    }
     T.f0 = f0 * rj;
-    T.f0Step = r2 * r2;
+    T.f0Step = r;
     T.axGeo = ax * qj;
-    T.axStep = q2 * q2;
+    T.axStep = q;
     T.glot0 = v0;
     T.glotDelta = dv;
     T.aspBase = prev[2];
     T.aspDelta = (cur[2] - prev[2]) * C.invControlPeriod;
+}
+TRM_HD void osc_slot_setup(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j)
+{
+    osc_slot_setup_pow2<2>(T, C, prev, cur, j);
 }
 
 // The representative of x (> -1) in (-1, 511]: what repeated `pos > 511 ? pos - 512 : pos` arrives at

@@ -23,6 +23,7 @@
 #include "trm_kernels.h"
 #include "trm_lane.h"
 #include "trm_quad.h"
+#include "trm_quad_dev.h"
 
 // Timing experiments (tools/bench_variants.sh) live behind ONE switch; the product build defines none of them.
 #ifndef TRM_EXPERIMENTS
@@ -41,40 +42,12 @@
 
 namespace trm {
 
-// The two LDS words through which the mix and convert waves hand coefficient rows to each other outside the step
-// barrier.  Publishing = LDS-only release fence (every lane: the rows were stored by all of them), then the flag;
-// consuming = the flag, then an LDS-only acquire fence.  "local": the fences order LDS traffic only -- a full
-// workgroup-scope release would also drain the convert wave's PCM stores (vmcnt), which nobody here reads.
-__device__ __forceinline__ void lds_flag_publish(uint32_t *flag, uint32_t value, bool writer)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (writer) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ uint32_t lds_flag_consume(uint32_t *flag)
-{
-    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    return v;
-}
-
 constexpr int kQV = 16;              // voices per workgroup
 constexpr int kQB = kSlots;          // tube samples per block = time slots per voice
 constexpr int kQRoles = 6;           // osc, mix, coef x2 (area | frication), tube, convert
-constexpr int kORing = 64;           // osc -> mix ring: (a, b) per tube sample
-constexpr int kOMirror = 32;         // slots 0..31 repeated after the ring: a 26-sample window never wraps
-constexpr int kOStride = kORing + kOMirror + 4;   // + 32 bytes: a row of lanes (4 voices x 2 distinct window starts) reads 8 different 16-byte bank groups
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
-// Hand-off depths in steps (x kSub blocks).  Block b of the mix wave's records lives in buffer b % (4 kSub): written
-// during step j+1, scanned during j+2, read by the tube during j+4 (its head during j+3).  The coefficient waves'
-// records live in buffer b % (3 kSub): written during step j+2, read during j+4 (head: j+3).
-constexpr int kXDepth = 4, kKDepth = 3;
-constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS: block B in buffer B % 3
-constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes apart, so that 16 lanes reading 16 rows hit 16 bank groups
-constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
-                                     // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
-
 // kStream: the launch is a chunk of a streamed utterance (state restored / saved); a compile-time switch so that
 // the one-shot instance carries none of it.
 // LDS layout of one workgroup, carved out of ONE dynamically sized array: with static __shared__ arrays the compiler

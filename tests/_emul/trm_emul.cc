@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../gnuspeech_amd/csrc/trm_lane.h"
+#include "../../gnuspeech_amd/csrc/trm_oct.h"
 #include "../../gnuspeech_amd/csrc/trm_setup.h"
 
 using namespace trm;
@@ -251,6 +252,75 @@ extern "C" int trm_emul_quad_selfcheck(const trm_input_params *p, int iters, uns
                              B3.v[3], T3.v[2], B3.v[2], QS.eB.y.v[2]};
         for (size_t i = 0; i < sizeof(exp_) / sizeof(exp_[0]); i++)
             if (exp_[i] != got[i]) { if (bad < 5) fprintf(stderr, "it %d: state %zu: %g vs %g\n", it, i, got[i], exp_[i]); bad++; }
+    }
+    return bad;
+}
+
+// tube_oct_core (eight parts per voice, trm_oct.h) against tube_step on random state / coefficients: the number of
+// mismatching values over `iters` steps (0 = the data movement is exact; a value taken from outside the voice's eight
+// lanes would be NaN here).
+extern "C" int trm_emul_oct_selfcheck(const trm_input_params *p, int iters, unsigned seed)
+{
+    Const C;
+    trm_derived d;
+    if (build_const(*p, C, d)) return -1;
+    srand(seed);
+    auto rnd = [&]() { return (float)rand() / (float)RAND_MAX * 2.0f - 1.0f; };
+    TubeState TS; tube_reset(TS);
+    OctState<O8> OS; oct_reset(OS);
+    OctLane<O8> L;
+    for (int i = 0; i < 8; i++) {
+        L.p0.v[i] = i == 0; L.p1.v[i] = i == 1; L.p5.v[i] = i == 5; L.end.v[i] = i == 4 || i == 7;
+        L.cf.v[i] = i == 4 ? C.mCoeff : i == 7 ? C.nCoeff : 0.0f;
+    }
+    float bx1 = 0, bx2 = 0, by1 = 0, by2 = 0, thY = 0;
+    int bad = 0;
+    for (int it = 0; it < iters; it++) {
+        if (it % 200 == 0) { tube_reset(TS); oct_reset(OS); bx1 = bx2 = by1 = by2 = thY = 0; }
+        Coefs K;
+        for (int i = 0; i < 7; i++) K.td[i] = (1.0f + rnd() * 0.9f) * C.damping;
+        K.onePlusK8 = 1.0f + rnd() * 0.9f;
+        K.k8a = (K.onePlusK8 - 1.0f) * C.mA10;
+        K.alphaU = rnd() * 0.5f + 0.5f;
+        K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);
+        K.ntd1 = (1.0f + rnd() * 0.9f) * C.damping;
+        for (int i = 0; i < 8; i++) K.tap[i] = rnd() * 0.1f;
+        K.bpBeta = 0.2f + rnd() * 0.2f; K.bpGamma = rnd() * 0.3f; K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
+        Excitation E; E.gin = rnd(); E.sig = rnd(); E.thr = rnd();
+        float y0 = tube_sample(TS, C, E, K);
+        // the two feed-forward recurrences as the kernel's other waves run them
+        SharedRecord H;
+        pack_shared_bp(K, H);
+        const float fr = bandpass_eval<float>(H.bpA2, H.bpB2, H.bpG2, E.sig, bx2, by1, by2);
+        bx2 = bx1; bx1 = E.sig; by2 = by1; by1 = fr;
+        const float ty = throat_eval<float>(C, E.thr, thY);
+        thY = ty;
+        float kk[8][2], tp[5][2];
+        pack_oct_k(K, C, kk);
+        pack_oct_tap(K, tp);
+        O8P k, in;
+        for (int q = 0; q < 8; q++) {
+            k.x.v[q] = kk[q][0]; k.y.v[q] = kk[q][1];
+            in.x.v[q] = q < 5 ? tp[q][0] * fr : 0.0f;
+            in.y.v[q] = q < 4 ? tp[q][1] * fr : q == 4 ? K.onePlusK8 : q == 7 ? C.onePlusNK6 : 0.0f;
+        }
+        O8 y = tube_oct_core(OS, O8(C.damping), O8(C.throatGain), L, O8(E.gin), O8(ty), k, in);
+        if (!(y.v[4] == y0)) { if (bad < 5) fprintf(stderr, "it %d: y %g vs %g\n", it, y.v[4], y0); bad++; }
+        const Waves &w = TS.w;
+        const float expT[8][2] = {{w.oT[1], w.oT[2]}, {w.oT[3], w.oT[4]}, {w.oT[5], w.oT[6]}, {w.oT[7], w.oT[8]},
+                                  {w.oT[9], 0}, {w.nT[1], w.nT[2]}, {w.nT[3], w.nT[4]}, {w.nT[5], 0}};
+        const float expB[8][2] = {{w.oB[0], w.oB[1]}, {w.oB[2], w.oB[3]}, {w.oB[4], w.oB[5]}, {w.oB[6], w.oB[7]},
+                                  {w.oB[8], w.oB[9]}, {w.nB[0], w.nB[1]}, {w.nB[2], w.nB[3]}, {w.nB[4], w.nB[5]}};
+        for (int q = 0; q < 8; q++) {
+            const bool endPart = q == 4 || q == 7;
+            if (!(OS.T.x.v[q] == expT[q][0]) || (!endPart && !(OS.T.y.v[q] == expT[q][1])) || !(OS.B.x.v[q] == expB[q][0]) ||
+                !(OS.B.y.v[q] == expB[q][1])) {
+                if (bad < 5) fprintf(stderr, "it %d: part %d: T {%g %g} vs {%g %g}, B {%g %g} vs {%g %g}\n", it, q, OS.T.x.v[q], OS.T.y.v[q],
+                                     expT[q][0], expT[q][1], OS.B.x.v[q], OS.B.y.v[q], expB[q][0], expB[q][1]);
+                bad++;
+            }
+        }
+        if (!(OS.A0.v[0] == w.oT[0]) || !(OS.jN.v[1] == w.nT[0])) { if (bad < 5) fprintf(stderr, "it %d: glottis / nasal branch\n", it); bad++; }
     }
     return bad;
 }
