@@ -93,7 +93,10 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     const int lane = threadIdx.x & (kWave - 1);
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifndef TRM_OCT_ROLE_PERM
-#define TRM_OCT_ROLE_PERM 1, 5, 0, 4, 2, 3      /* mix convert osc tube | coef-area coef-fric (waves w and w+4 of a workgroup share a SIMD) */
+#define TRM_OCT_ROLE_PERM 0, 1, 3, 4, 2, 5      /* osc mix fric tube | area convert: waves w and w+4 of a workgroup share a SIMD, the
+                                                   frication and tube waves have one to themselves (and the other workgroup's
+                                                   waves for company); of 20 assignments tried this is the fastest by 1-10 %
+                                                   (profiles/oct_variants_r02.txt) */
 #endif
     const int rolePerm[kORoles] = {TRM_OCT_ROLE_PERM};
     int role = 0;
@@ -418,9 +421,12 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         STAMP_STORE(role)
     } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
-#ifdef TRM_OCT_TUBE_PRIO
-        __builtin_amdgcn_s_setprio(TRM_OCT_TUBE_PRIO);
+        // the only serial role: its instructions go first on the SIMD it shares with the other workgroup's waves
+        // (2.89 -> 2.74 ms with the first role assignment, 3.21 -> 2.58 with this one)
+#ifndef TRM_OCT_TUBE_PRIO
+#define TRM_OCT_TUBE_PRIO 3
 #endif
+        __builtin_amdgcn_s_setprio(TRM_OCT_TUBE_PRIO);
         const int pT = lane & 7;
         OctLane<float> OL;
         OL.p0 = pT == 0; OL.p1 = pT == 1; OL.p5 = pT == 5; OL.end = pT == 4 || pT == 7;
