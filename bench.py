@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KERNEL_SOURCES = ("trm_quad.hip", "trm_quad.h", "trm_kernels.hip", "trm_lane.h", "trm_devutil.h", "trm_kernels.h", "Makefile")
+KERNEL_SOURCES = ("trm_oct.hip", "trm_oct.h", "trm_quad.hip", "trm_quad.h", "trm_quad_dev.h", "trm_kernels.hip", "trm_lane.h", "trm_devutil.h", "trm_kernels.h",
+                  "Makefile")
 
 
 def kernel_source_hash():
@@ -121,7 +122,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=["static", "timevarying"],
                     help="default: static at --gpus 1 (configs[1]), timevarying at --gpus N (configs[4]: config-3 voices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "quad"],
+    ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "quad", "oct"],
                     help="kernel form (include/trm_c_api.h); auto = the library's choice by batch size")
     a = ap.parse_args()
 
@@ -247,7 +248,7 @@ def main():
                    "kernel_form": b.last_kernel},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": {"wide": "trm_tube_kernel", "quad": "trm_tube_kernel_q"}[b.last_kernel], "avg_launch_ms": kern_ms / max(1, launches),
+                     "kernel": {"wide": "trm_tube_kernel", "quad": "trm_tube_kernel_q", "oct": "trm_tube_kernel_o"}[b.last_kernel], "avg_launch_ms": kern_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
                      "note": "VALU-issue bound scalar recurrence (SURVEY 8d); HBM-write fraction reported as BASELINE asks"},
         "cpu_baseline": cpu,

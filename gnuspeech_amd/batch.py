@@ -194,8 +194,8 @@ class TRMBatch:
         return out
 
     def set_kernel(self, kernel):
-        """'auto' | 'wide' (one voice per lane) | 'quad' (four lanes per voice); see include/trm_c_api.h."""
-        check(lib().trm_batch_set_kernel(self._h, {"auto": 0, "wide": 1, "quad": 2}[kernel]))
+        """'auto' | 'wide' (one voice per lane) | 'quad' (four lanes per voice) | 'oct' (eight); see include/trm_c_api.h."""
+        check(lib().trm_batch_set_kernel(self._h, {"auto": 0, "wide": 1, "quad": 2, "oct": 3}[kernel]))
 
     def set_timing(self, on):
         """Launch timing on / off; off, synthesize_device is pure stream work and can be captured into a HIP graph."""
@@ -203,7 +203,7 @@ class TRMBatch:
 
     @property
     def last_kernel(self):
-        return {0: "auto", 1: "wide", 2: "quad"}[lib().trm_batch_last_kernel(self._h)]
+        return {0: "auto", 1: "wide", 2: "quad", 3: "oct"}[lib().trm_batch_last_kernel(self._h)]
 
     def kernel_time_ms(self):
         t = C.c_double()

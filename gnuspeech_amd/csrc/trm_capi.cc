@@ -102,7 +102,6 @@ struct trm_batch {
     int lastKernel = TRM_KERNEL_AUTO;    // what the last launch ran
     int cus = 0;                         // compute units of the device (set at create)
     int envKernel = TRM_KERNEL_AUTO;     // TRM_TUBE_KERNEL, read once at create (steers launches left on AUTO; tests)
-    bool oct = false;                    // TRM_QUAD_OCT (tests / experiments for now): small batches of TRM_KERNEL_QUAD run trm_oct.hip's kernel
     bool envDownGeneric = false;         // TRM_DOWNSAMPLE_GENERIC, read once at create (tests: the generic down-sampling kernel)
     size_t tubeOffVoices = 0;            // dTubeOff holds pitch * v for v < tubeOffVoices ...
     uint64_t tubeOffPitch = 0;           // ... at this row pitch (down-sampling batches: rebuilt only when either changes)
@@ -194,8 +193,7 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     // (tests and experiments: 0 = the four-lane form always with two blocks per pipeline step, 1 = always with one --
     // tests/test_gpu_parity.py runs every parity test in that instance too)
     if (const char *e = getenv("TRM_QUAD_CUS")) b->cus = atoi(e);
-    if (const char *e = getenv("TRM_TUBE_KERNEL")) b->envKernel = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : TRM_KERNEL_AUTO;
-    if (const char *e = getenv("TRM_QUAD_OCT")) b->oct = atoi(e) != 0;
+    if (const char *e = getenv("TRM_TUBE_KERNEL")) b->envKernel = !strcmp(e, "wide") ? TRM_KERNEL_WIDE : !strcmp(e, "quad") ? TRM_KERNEL_QUAD : !strcmp(e, "oct") ? TRM_KERNEL_OCT : TRM_KERNEL_AUTO;
     b->envDownGeneric = getenv("TRM_DOWNSAMPLE_GENERIC") != nullptr;
     hipError_t e;
 #define B_TRY(expr)                                                              \
@@ -465,22 +463,23 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    // Kernel form: one voice per lane (64 voices per workgroup) once that alone puts two workgroups on
-    // every CU; below that, four lanes per voice (16 voices per workgroup), which advances four tube
-    // samples per pass of the instruction streams and spreads a small batch over four times the CUs.
+    // Kernel form: one voice per lane (64 voices per workgroup) once that alone puts two workgroups on every CU; below
+    // that, several lanes per voice, which advances several tube samples per pass of the instruction streams and spreads
+    // a small batch over more CUs: eight lanes (8 voices per workgroup) while two such workgroups per CU hold the
+    // batch, four lanes (16 voices per workgroup) from there on.
+    // (trm_oct.hip's feed-forward waves step 8 samples at a time: a control period must hold at least that many)
+    const bool octFits = b->c.controlPeriod >= 8 && b->cus > 0 && (nvoices + 7) / 8 <= 2 * (size_t)b->cus;
     int which = b->kernel;
     if (which == TRM_KERNEL_AUTO) which = b->envKernel;
-    if (which == TRM_KERNEL_AUTO) which = nvoices >= (size_t)b->wideThreshold ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD;
-    // The four-lane form's converter is fed one block of coefficient rows per step by design (two at a push): four
-    // outputs per tube sample.  It measured clean to 5.3 and wrong from 5.6 on (the ring laps the converter;
-    // tools/fuzz_parity.py at 96 kHz), so above 4 -- 96 kHz output from any adult tube, 64 kHz from 22 cm on -- the
-    // one-voice-per-lane form runs, whatever was asked for.
-    if (which == TRM_KERNEL_QUAD && quad_ratio_too_high(b->c)) which = TRM_KERNEL_WIDE;
+    if (which == TRM_KERNEL_AUTO) which = nvoices >= (size_t)b->wideThreshold ? TRM_KERNEL_WIDE : octFits ? TRM_KERNEL_OCT : TRM_KERNEL_QUAD;
+    if (which == TRM_KERNEL_OCT && !octFits) which = TRM_KERNEL_QUAD;
+    // The converter of the forms with several lanes per voice is fed one block of coefficient rows per step by design
+    // (two at a push): four outputs per tube sample.  It measured clean to 5.3 and wrong from 5.6 on (the ring laps the
+    // converter; tools/fuzz_parity.py at 96 kHz), so above 4 -- 96 kHz output from any adult tube, 64 kHz from 22 cm on --
+    // the one-voice-per-lane form runs, whatever was asked for.
+    if (which != TRM_KERNEL_WIDE && quad_ratio_too_high(b->c)) which = TRM_KERNEL_WIDE;
     b->lastKernel = which;
-    // Batches of at most two 8-voice workgroups per CU: the instance with eight lanes per voice (trm_oct.hip; its
-    // feed-forward waves step 8 samples at a time, so a control period must hold at least that many)
-    const bool oct = b->oct && b->c.controlPeriod >= 8 && b->cus > 0 && (nvoices + 7) / 8 <= 2 * (size_t)b->cus;
-    if (which == TRM_KERNEL_QUAD && oct)
+    if (which == TRM_KERNEL_OCT)
         HIP_TRY(trm::launch_tube_oct(b->c, a, stream));
     else if (which == TRM_KERNEL_QUAD)
         HIP_TRY(trm::launch_tube_quad(b->c, a, stream, b->cus));
@@ -747,7 +746,7 @@ int trm_stream_finish(trm_stream *s, float *out, size_t out_pitch, uint32_t *nou
 int trm_batch_set_kernel(trm_batch *b, int kernel)
 {
     if (!b) return fail(TRM_EINVAL, "null batch");
-    if (kernel != TRM_KERNEL_AUTO && kernel != TRM_KERNEL_WIDE && kernel != TRM_KERNEL_QUAD) return fail(TRM_EINVAL, "unknown kernel form %d", kernel);
+    if (kernel != TRM_KERNEL_AUTO && kernel != TRM_KERNEL_WIDE && kernel != TRM_KERNEL_QUAD && kernel != TRM_KERNEL_OCT) return fail(TRM_EINVAL, "unknown kernel form %d", kernel);
     b->kernel = kernel;
     return TRM_OK;
 }

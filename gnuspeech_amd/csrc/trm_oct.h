@@ -117,12 +117,13 @@ TRM_HD void oct_reset(OctState<F> &S)
     S.A0 = S.jN = S.reflY = S.radX = S.radY = z;
 }
 
-// One tube sample: `gin` the glottal input, `ty` the throat output of that sample (voice-wide values), k / in this
-// part's record; d = C.damping, tg = C.throatGain (parameters so that the kernel can hand them over in VECTOR registers:
+// One tube sample: `gin` the glottal input, `ty` the throat output of that sample, `aLR` the three-way junction's
+// alpha-left = alpha-right (voice-wide values; part 0 uses gin, part 1 aLR, part 4 ty: the kernel hands each part ITS
+// value in one register), k / in this part's record; d = C.damping, tg = C.throatGain (parameters so that the kernel can hand them over in VECTOR registers:
 // an instruction with a scalar-register operand does not co-issue with another wave's, profiles/valu_ceiling_r02.txt).
 // Returns the tube-rate output in PART 4 (other parts: unspecified).
 template <class F>
-TRM_HD F tube_oct_core(OctState<F> &S, F d, F tg, const OctLane<F> &L, F gin, F ty, typename PairOf<F>::type k,
+TRM_HD F tube_oct_core(OctState<F> &S, F d, F tg, const OctLane<F> &L, F gin, F ty, F aLR, typename PairOf<F>::type k,
                        typename PairOf<F>::type in)
 {
     typedef typename PairOf<F>::type P;
@@ -143,7 +144,7 @@ TRM_HD F tube_oct_core(OctState<F> &S, F d, F tg, const OctLane<F> &L, F gin, F 
     // ---- glottis end (:781)
     S.A0 = S.B.x * d + gin;
     // ---- three-way junction (:801-806); the three alphas sum to 2 (:733-736)
-    const F aU = k.y, aLR = fma_f(F(-0.5f), aU, F(1.0f));
+    const F aU = k.y;
     const F jp = aLR * tX + (aLR * bY + aU * x3);
     const F jB = (jp - tX) * d;
     const F jT = (jp - bY) * d + in.y;

@@ -401,6 +401,8 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                     pack_oct_k(K, C, kk);
                     for (int p = 0; p < 6; p++) reinterpret_cast<float2 *>(&row[p * kOPartPitch])[0] = make_float2(kk[p][0], kk[p][1]);
                     reinterpret_cast<float *>(&row[4 * kOPartPitch])[3] = K.onePlusK8;
+                    // the three-way junction's alpha-left/right rides in the free word of the mix wave's record (written a step ago)
+                    reinterpret_cast<float *>(&sX[((blk % kXDepth) * kOB + slot) * kOXPitch + vq])[3] = K.alphaLR;
                 } else {
                     coef_sample_fric(K, T, C, (int)j);
                     float tp[5][2];
@@ -438,21 +440,24 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         oct_reset(S);
         float4 *const ring = reinterpret_cast<float4 *>(&sY[vq * kYStride]);
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
-        // one sample's inputs: this part's record {k | injections}, the voice's {gin, -, throat output}
-        struct In { float4 r, x; };
+        // one sample's inputs: this part's record {k | injections} and the ONE word of the voice's record {gin, -, throat
+        // output, alpha-left/right} this part uses (part 0: gin, part 1: alpha, part 4: the throat output)
+        struct In { float4 r; float xs; };
+        const int xWord = pT == 0 ? 0 : pT == 1 ? 3 : 2;
         auto load_in = [&](uint32_t blk, int s) {
             In r;
             r.r = sK[((blk % kKDepth) * kOB + s) * kOKRow + pT * kOPartPitch + vq];
-            r.x = sX[((blk % kXDepth) * kOB + s) * kOXPitch + vq];
+            r.xs = reinterpret_cast<const float *>(&sX[((blk % kXDepth) * kOB + s) * kOXPitch + vq])[xWord];
             return r;
         };
         auto step_one = [&](const In &r) {
-            return tube_oct_core<float>(S, dV, tgV, OL, r.x.x, r.x.z, v2f_t{r.r.x, r.r.y}, v2f_t{r.r.z, r.r.w});
+            return tube_oct_core<float>(S, dV, tgV, OL, r.xs, r.xs, r.xs, v2f_t{r.r.x, r.r.y}, v2f_t{r.r.z, r.r.w});
         };
         // A block's first sample's inputs are fetched behind the last sample of the block before it (during step i-1),
         // the others land behind the first samples' arithmetic: no LDS latency is exposed.
         In head;
-        head.r = head.x = make_float4(0.f, 0.f, 0.f, 0.f);
+        head.r = make_float4(0.f, 0.f, 0.f, 0.f);
+        head.xs = 0.f;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
@@ -477,6 +482,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                     y[7] = step_one(i7);
                 }
                 if (n0 + kOB > ntubeMin) {     // (uniform) zero flush / voices shorter than the group's longest
+                    asm volatile("");          // (a real branch: if-converted, the selects run on every sample of every step)
 #pragma unroll
                     for (int s = 0; s < kOB; s++) y[s] = n0 + s < ntubeLane ? y[s] : 0.0f;
                 }

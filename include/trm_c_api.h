@@ -324,15 +324,19 @@ int  trm_stream_push(trm_stream *stream, const float *frames, size_t nframes, fl
  * can then start a new utterance with its next push. */
 int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_t *nout, float *max_out);
 
-/* Kernel form of the synthesis launch.  Both forms compute the same samples (same arithmetic per value);
+/* Kernel form of the synthesis launch.  All forms compute the same samples (same arithmetic per value);
  * they differ in how a voice is laid out on the machine:
  *   TRM_KERNEL_WIDE  one voice per lane, 64 voices per workgroup: highest throughput once the batch fills
  *                    the chip (AUTO: above 32 voices per CU, 8192 on MI355X);
- *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: lowest latency for smaller batches.
- * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad
+ *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: mid-size batches (AUTO: above 16 voices per CU)
+ *                    and every stream (trm_stream_*);
+ *   TRM_KERNEL_OCT   eight lanes per voice, 8 voices per workgroup, two workgroups per CU: lowest latency for
+ *                    batches of up to 16 voices per CU (4096 on MI355X).  Needs a control period of at least 8 tube
+ *                    samples; where it does not apply (longer batches, shorter periods) TRM_KERNEL_QUAD runs instead.
+ * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad|oct
  * overrides AUTO (diagnostics).  Parameters with more than four output samples per tube sample (96 kHz output)
  * always run TRM_KERNEL_WIDE.  No reference counterpart: the reference runs one tube per thread. */
-enum { TRM_KERNEL_AUTO = 0, TRM_KERNEL_WIDE = 1, TRM_KERNEL_QUAD = 2 };
+enum { TRM_KERNEL_AUTO = 0, TRM_KERNEL_WIDE = 1, TRM_KERNEL_QUAD = 2, TRM_KERNEL_OCT = 3 };
 int  trm_batch_set_kernel(trm_batch *batch, int kernel);
 int  trm_batch_last_kernel(const trm_batch *batch);
 

@@ -304,7 +304,7 @@ extern "C" int trm_emul_oct_selfcheck(const trm_input_params *p, int iters, unsi
             in.x.v[q] = q < 5 ? tp[q][0] * fr : 0.0f;
             in.y.v[q] = q < 4 ? tp[q][1] * fr : q == 4 ? K.onePlusK8 : q == 7 ? C.onePlusNK6 : 0.0f;
         }
-        O8 y = tube_oct_core(OS, O8(C.damping), O8(C.throatGain), L, O8(E.gin), O8(ty), k, in);
+        O8 y = tube_oct_core(OS, O8(C.damping), O8(C.throatGain), L, O8(E.gin), O8(ty), O8(K.alphaLR), k, in);
         if (!(y.v[4] == y0)) { if (bad < 5) fprintf(stderr, "it %d: y %g vs %g\n", it, y.v[4], y0); bad++; }
         const Waves &w = TS.w;
         const float expT[8][2] = {{w.oT[1], w.oT[2]}, {w.oT[3], w.oT[4]}, {w.oT[5], w.oT[6]}, {w.oT[7], w.oT[8]},

@@ -168,4 +168,4 @@ def test_bench_traffic_file_is_stamped_with_the_kernel_sources():
     assert len(h) == 16 and int(h, 16) >= 0
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
     assert set(("kernel_source_sha16", "workload", "traffic_bytes_per_launch", "SQ_INSTS_VALU", "issue_cycles_per_valu")) <= set(tj)
-    assert tj["workload"]["kernel_form"] in ("quad", "wide")
+    assert tj["workload"]["kernel_form"] in ("oct", "quad", "wide")

@@ -32,13 +32,12 @@ def g():
 
 @pytest.fixture(params=["wide", "quad", "quad1", "oct"])
 def form(request, monkeypatch):
-    """Every kernel form must meet the same bar (include/trm_c_api.h): one voice per lane, four lanes per voice, and the
-    four-lane form's second instance ("quad1": one block per pipeline step, the one that lets two workgroups share a CU and
-    that batches of more than 16 voices x CUs run; TRM_QUAD_CUS=1 makes every batch take it).  TRM_TUBE_KERNEL steers every
-    launch that is left on TRM_KERNEL_AUTO; both variables are read when a batch object is created.  "oct": the four-lane
-    form's instance whose tube stage is two waves with eight lanes per voice (TRM_QUAD_OCT=1)."""
-    monkeypatch.setenv("TRM_TUBE_KERNEL", "quad" if request.param in ("quad1", "oct") else request.param)
-    monkeypatch.setenv("TRM_QUAD_OCT", "1" if request.param == "oct" else "0")
+    """Every kernel form must meet the same bar (include/trm_c_api.h): one voice per lane, four lanes per voice, eight lanes
+    per voice, and the four-lane form's second instance ("quad1": one block per pipeline step, the one that lets two
+    workgroups share a CU and that batches of more than 16 voices x CUs run; TRM_QUAD_CUS=1 makes every batch take it).
+    TRM_TUBE_KERNEL steers every launch that is left on TRM_KERNEL_AUTO; both variables are read when a batch object is
+    created."""
+    monkeypatch.setenv("TRM_TUBE_KERNEL", "quad" if request.param == "quad1" else request.param)
     if request.param == "quad1":
         monkeypatch.setenv("TRM_QUAD_CUS", "1")
     else:

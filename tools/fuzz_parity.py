@@ -48,7 +48,7 @@ for seed in range(first, last):
             pass
         continue
     if os.environ.get("FUZZ_ORACLE_ONLY"): continue
-    for form in ("wide", "quad"):
+    for form in ("wide", "quad", "oct"):
         try:
             b = g.TRMBatch(g.TRMInputParameters.from_dict(pd)); b.set_kernel(form)
             pcm, ns, mx = b.synthesize(voices)

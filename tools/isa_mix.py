@@ -7,12 +7,12 @@
 Compiles the kernel source to assembly with the product's flags and splits each kernel at its step barriers: the piece
 in front of a barrier that lies inside a loop is one role's per-step body (period-boundary blocks included: they run
 once per control period, so the per-step figures are slight over-counts).
-usage: isa_mix.py [quad|wide]"""
+usage: isa_mix.py [quad|oct|wide]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 which = sys.argv[1] if len(sys.argv) > 1 else "quad"
-src = {"quad": "trm_quad.hip", "wide": "trm_kernels.hip"}[which]
-flags = ["-O3", "-std=c++17", "-fno-slp-vectorize"] + (["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] if which == "quad" else [])
+src = {"quad": "trm_quad.hip", "oct": "trm_oct.hip", "wide": "trm_kernels.hip"}[which]
+flags = ["-O3", "-std=c++17", "-fno-slp-vectorize"] + (["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] if which != "wide" else [])
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "--offload-device-only", "-S", "-o", out] + flags + [os.path.join(ROOT, "gnuspeech_amd", "csrc", src)],

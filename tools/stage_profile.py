@@ -29,8 +29,8 @@ for _ in range(2):
     b.synthesize_device(st)
 torch.cuda.synchronize()
 L = g.lib()
-quad = b.last_kernel == "quad"
-octInst = quad and os.environ.get("TRM_QUAD_OCT", "0") != "0" and (V + 7) // 8 <= 512     # eight lanes per voice, 8 voices per workgroup
+quad = b.last_kernel in ("quad", "oct")
+octInst = b.last_kernel == "oct"     # eight lanes per voice, 8 voices per workgroup
 nwg = (V + 7) // 8 if octInst else (V + 15) // 16 if quad else (V + 63) // 64
 NR = 6 if quad else 7
 buf = np.zeros(nwg * NR * 8, dtype=np.uint64)
