@@ -24,6 +24,9 @@ python bench.py --steps 5 --warmup 2 --no-cpu-baseline --voices 8192 --workload 
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --workload timevarying > $O/bench_4096_timevarying.json 2>/dev/null
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --voices 65536 > $O/bench_65536.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel wide > $O/bench_wide4096.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel quad > $O/bench_quad4096.json 2>/dev/null
+bash tools/sweep_oct.sh > $O/sweep_oct.txt 2>/dev/null
+python tools/stage_profile.py 4096 0.25 static oct > $O/stage_profile_oct.txt 2>/dev/null
 python tools/stage_profile.py 4096 0.25 static quad > $O/stage_profile_quad.txt 2>/dev/null
 python tools/stage_profile.py 8192 0.25 static quad > $O/stage_profile_quad_8192.txt 2>/dev/null
 python tools/stage_profile.py 4096 0.25 static wide > $O/stage_profile_wide.txt 2>/dev/null
@@ -32,4 +35,4 @@ python tools/bench_configs.py > $O/configs.txt 2>/dev/null
 python tools/host_path_rate.py > $O/host_path.txt 2>/dev/null
 tools/ubench/valu_ceiling > $O/valu_ceiling.txt 2>/dev/null || true
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds $O/pmc_cls $O/pmc_cls2 $O/*.log
-cat $O/summary.txt; cat $O/stage_profile_quad.txt; cat $O/sweep_forms.txt; cut -c1-250 $O/bench_default.json $O/bench_65536.json $O/bench_wide4096.json
+cat $O/summary.txt; cat $O/stage_profile_oct.txt; cat $O/sweep_forms.txt; cut -c1-250 $O/bench_default.json $O/bench_65536.json $O/bench_wide4096.json
