@@ -34,19 +34,28 @@ namespace trm {
 constexpr int kOV = 8;               // voices per workgroup
 constexpr int kOB = 8;               // tube samples per step = time slots per voice (two blocks of kSlots)
 constexpr int kORoles = 6;           // osc, mix, coef x2 (area | frication), tube, convert
-constexpr int kOXPitch = kOV + 4;    // mix -> tube: float4s per (buffer, sample) of the per-voice records (+ 64 bytes: the
-                                     // writers' time slots fall in different LDS banks)
-constexpr int kOPartPitch = kOV + 2; // coef -> tube: a part's row of 8 voices + 2 records, so that 16 consecutive lanes of
-                                     // the tube wave (2 voices x 8 parts) read 16 different 16-byte bank groups
-constexpr int kOKRow = 8 * kOPartPitch + 4;      // float4s per (buffer, sample) of the coefficient records
+// mix -> tube: the per-voice values of a sample as FOUR arrays [buffer][slot][voice] of floats -- glottal input, noise
+// signal, throat input / output, the three-way junction's alpha -- so that a wave's 32-lane groups touch 32 consecutive
+// dwords (one float4 record per voice put 32 lanes on 8 banks); the arrays start 8 banks apart: the tube wave's parts read
+// three of them in one instruction
+constexpr int kOXArray = kXDepth * kOB * kOV + 8;
+enum { kXGin = 0, kXSig = 1, kXThr = 2, kXAlpha = 3 };
+// coef -> tube: one float4 record {k.x, k.y | in.x, in.y} per (sample, part, voice).  ds_read_b128 serves a wave in four
+// groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS) -- which for
+// the tube wave's lanes (voice v = lane / 8, part p = lane % 8) are four blocks {4 parts of one voice}: this index gives
+// every lane of a group its own 16-byte bank slot 4 (p & 3) + (v & 3)  (the first layout, part rows of 8 + 2 records,
+// was 2-way conflicted there: SQ_LDS_BANK_CONFLICT 1.4e8 -> see profiles/)
+__host__ __device__ constexpr int oct_k_index(int p, int v) { return 16 * ((p >> 2) * 2 + (v >> 2)) + 4 * (p & 3) + (v & 3); }
+constexpr int kOKRow = 64 + 4;       // float4s per (buffer, sample): 64 records + 64 bytes, so that the writers' time slots
+                                     // alternate between the two halves of the 32 write banks
 
 // LDS of one workgroup, one dynamically sized array (see trm_quad.hip: a static size makes the compiler pad the VGPR
 // allocation for "three waves per SIMD", and two co-resident workgroups then do not fit)
 struct OctLds {
     static constexpr size_t oO = 0;                                                       // float2 [kOV * kOStride]
     static constexpr size_t oA = oO + sizeof(float2) * kOV * kOStride;                    // float2 [2 * kWave]
-    static constexpr size_t oX = oA + sizeof(float2) * 2 * kWave;                         // float4 [kXDepth * kOB * kOXPitch]
-    static constexpr size_t oK = oX + sizeof(float4) * kXDepth * kOB * kOXPitch;          // float4 [kKDepth * kOB * kOKRow]
+    static constexpr size_t oX = oA + sizeof(float2) * 2 * kWave;                         // float  [4 * kOXArray]
+    static constexpr size_t oK = oX + sizeof(float) * 4 * kOXArray;                       // float4 [kKDepth * kOB * kOKRow]
     static constexpr size_t oY = oK + sizeof(float4) * kKDepth * kOB * kOKRow;            // float  [kOV * kYStride]
     static constexpr size_t oRows = oY + sizeof(float) * kOV * kYStride;                  // float  [kRowBufs * kCvtCols * kRowPitch]
     static constexpr size_t oInfo = oRows + sizeof(float) * kRowBufs * kCvtCols * kRowPitch;   // uint4 [kOV]
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     extern __shared__ __attribute__((aligned(16))) unsigned char sLds[];
     float2 *const sO = reinterpret_cast<float2 *>(sLds + L::oO);           // osc -> mix: oscillator reads
     float2 *const sA = reinterpret_cast<float2 *>(sLds + L::oA);           // osc -> mix: {ax, ah1} per (step & 1, lane)
-    float4 *const sX = reinterpret_cast<float4 *>(sLds + L::oX);           // mix -> tube: {gin, sig, thr} [buf][slot][voice]
+    float *const sX = reinterpret_cast<float *>(sLds + L::oX);             // mix -> tube: [gin | sig | thr | alpha][buf][slot][voice]
     float4 *const sK = reinterpret_cast<float4 *>(sLds + L::oK);           // coef -> tube: {k | injections} [buf][slot][part][voice]
     float *const sY = reinterpret_cast<float *>(sLds + L::oY);             // tube-rate rings
     float *const sRows = reinterpret_cast<float *>(sLds + L::oRows);       // mix -> convert: coefficient rows of 3 blocks
@@ -125,6 +134,8 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
     auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
+    // where sample `s` of block `blk` keeps this lane's voice's value of array `arr`
+    auto x_at = [&](int arr, uint32_t blk, int s) -> float & { return sX[arr * kOXArray + ((blk % kXDepth) * kOB + s) * kOV + vq]; };
 
     for (int i = threadIdx.x; i < kOV * kYStride; i += kThreads) sY[i] = 0.0f;
     for (int i = threadIdx.x; i < kOV * kOStride; i += kThreads) sO[i] = make_float2(0.0f, 0.0f);
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     __syncthreads();
     // what no wave writes per sample: the nasal tract's constant records (parts 6, 7; part 5's injections stay 0)
     for (int i = threadIdx.x; i < kKDepth * kOB * kOV; i += kThreads) {
-        float4 *row = &sK[(i / kOV) * kOKRow + (i % kOV)];
-        row[6 * kOPartPitch] = make_float4(C.nasalTd[1], C.nasalTd[2], 0.0f, 0.0f);
-        row[7 * kOPartPitch] = make_float4(C.nasalTd[3], C.nasalK6a, 0.0f, C.onePlusNK6);
+        float4 *row = &sK[(i / kOV) * kOKRow];
+        row[oct_k_index(6, i % kOV)] = make_float4(C.nasalTd[1], C.nasalTd[2], 0.0f, 0.0f);
+        row[oct_k_index(7, i % kOV)] = make_float4(C.nasalTd[3], C.nasalK6a, 0.0f, C.onePlusNK6);
     }
     __syncthreads();
 
@@ -230,8 +241,8 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
             STAMP_BEGIN
             // block i-2: the mix wave's {sig, thr} were written during step i-1; the tube wave reads the result from step i+1 on
             if (step >= 2 && (step - 2) * kOB < nTotal) {
-                float *const xr = reinterpret_cast<float *>(&sX[(((step - 2) % kXDepth) * kOB + slot) * kOXPitch + vq]);
-                xr[2] = throat_scan(Z, xr[2]);
+                float &thr = x_at(kXThr, step - 2, slot);
+                thr = throat_scan(Z, thr);
             }
             if (step * kOB < nTotal) {
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
@@ -354,7 +365,9 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                 const float2 a = sA[((step - 1) & 1u) * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
                 // (thr raw: the oscillator wave turns it into the throat output one step on)
-                sX[((((step - 1) % kXDepth) * kOB) + slot) * kOXPitch + vq] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                x_at(kXGin, step - 1, slot) = E.gin;
+                x_at(kXSig, step - 1, slot) = E.sig;
+                x_at(kXThr, step - 1, slot) = E.thr;
             }
             STAMP_MID
             step_barrier();
@@ -394,25 +407,24 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                 Coefs K;
                 // [buf][slot][part p][voice]{k.x, k.y | in.x, in.y}: the area wave writes the k halves (and the mouth
                 // end's 1 + C8), the frication wave the injections
-                float4 *row = &sK[((blk % kKDepth) * kOB + slot) * kOKRow + vq];
+                float4 *row = &sK[((blk % kKDepth) * kOB + slot) * kOKRow];
                 if (area) {
                     coef_sample_area(K, T, C, (int)j);
                     float kk[8][2];
                     pack_oct_k(K, C, kk);
-                    for (int p = 0; p < 6; p++) reinterpret_cast<float2 *>(&row[p * kOPartPitch])[0] = make_float2(kk[p][0], kk[p][1]);
-                    reinterpret_cast<float *>(&row[4 * kOPartPitch])[3] = K.onePlusK8;
-                    // the three-way junction's alpha-left/right rides in the free word of the mix wave's record (written a step ago)
-                    reinterpret_cast<float *>(&sX[((blk % kXDepth) * kOB + slot) * kOXPitch + vq])[3] = K.alphaLR;
+                    for (int p = 0; p < 6; p++) reinterpret_cast<float2 *>(&row[oct_k_index(p, vq)])[0] = make_float2(kk[p][0], kk[p][1]);
+                    reinterpret_cast<float *>(&row[oct_k_index(4, vq)])[3] = K.onePlusK8;
+                    x_at(kXAlpha, blk, slot) = K.alphaLR;     // the three-way junction's alpha-left = alpha-right
                 } else {
                     coef_sample_fric(K, T, C, (int)j);
                     float tp[5][2];
                     pack_oct_tap(K, tp);
                     SharedRecord H;
                     pack_shared_bp(K, H);
-                    const float sig = reinterpret_cast<const float *>(&sX[((blk % kXDepth) * kOB + slot) * kOXPitch + vq])[1];
+                    const float sig = x_at(kXSig, blk, slot);
                     const float f = bandpass_scan(Z, sig, make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f));
-                    for (int p = 0; p < 4; p++) reinterpret_cast<float2 *>(&row[p * kOPartPitch])[1] = make_float2(tp[p][0] * f, tp[p][1] * f);
-                    reinterpret_cast<float *>(&row[4 * kOPartPitch])[2] = tp[4][0] * f;
+                    for (int p = 0; p < 4; p++) reinterpret_cast<float2 *>(&row[oct_k_index(p, vq)])[1] = make_float2(tp[p][0] * f, tp[p][1] * f);
+                    reinterpret_cast<float *>(&row[oct_k_index(4, vq)])[2] = tp[4][0] * f;
                 }
                 j += kOB;
             }
@@ -440,14 +452,15 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         oct_reset(S);
         float4 *const ring = reinterpret_cast<float4 *>(&sY[vq * kYStride]);
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
-        // one sample's inputs: this part's record {k | injections} and the ONE word of the voice's record {gin, -, throat
-        // output, alpha-left/right} this part uses (part 0: gin, part 1: alpha, part 4: the throat output)
+        // one sample's inputs: this part's record {k | injections} and the ONE per-voice value this part uses (part 0: the
+        // glottal input, part 1: the three-way junction's alpha, part 4: the throat output)
         struct In { float4 r; float xs; };
-        const int xWord = pT == 0 ? 0 : pT == 1 ? 3 : 2;
+        const int xArr = pT == 0 ? kXGin : pT == 1 ? kXAlpha : kXThr;
+        const int kIdx = oct_k_index(pT, vq);
         auto load_in = [&](uint32_t blk, int s) {
             In r;
-            r.r = sK[((blk % kKDepth) * kOB + s) * kOKRow + pT * kOPartPitch + vq];
-            r.xs = reinterpret_cast<const float *>(&sX[((blk % kXDepth) * kOB + s) * kOXPitch + vq])[xWord];
+            r.r = sK[((blk % kKDepth) * kOB + s) * kOKRow + kIdx];
+            r.xs = x_at(xArr, blk, s);
             return r;
         };
         auto step_one = [&](const In &r) {
