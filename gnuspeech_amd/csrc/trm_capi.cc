@@ -467,8 +467,9 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // that, several lanes per voice, which advances several tube samples per pass of the instruction streams and spreads
     // a small batch over more CUs: eight lanes (8 voices per workgroup) while two such workgroups per CU hold the
     // batch, four lanes (16 voices per workgroup) from there on.
-    // (trm_oct.hip's feed-forward waves step 8 samples at a time: a control period must hold at least that many)
-    const bool octFits = b->c.controlPeriod >= 8 && b->cus > 0 && (nvoices + 7) / 8 <= 2 * (size_t)b->cus;
+    // (trm_oct.hip's feed-forward waves step 8 samples at a time and set a control period up while the lanes of the one
+    // before are still crossing into it: a control period must hold at least two steps)
+    const bool octFits = b->c.controlPeriod >= 16 && b->cus > 0 && (nvoices + 7) / 8 <= 2 * (size_t)b->cus;
     int which = b->kernel;
     if (which == TRM_KERNEL_AUTO) which = b->envKernel;
     if (which == TRM_KERNEL_AUTO) which = nvoices >= (size_t)b->wideThreshold ? TRM_KERNEL_WIDE : octFits ? TRM_KERNEL_OCT : TRM_KERNEL_QUAD;

@@ -223,16 +223,34 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     if (role == 0) {
         // ------------------------------------------------------------ osc: block i at step i, lane = (voice, slot)
         auto sine = [&](int i) { return sine_table(i); };
-        OscSlotTrack T;
+        // The control-period set-up (four fp64 exponentials) runs ONCE per period and wave: the lanes of a voice enter a
+        // period in two different steps (its first sample falls somewhere inside a step), so the step in which the first of
+        // them does sets the period's track up for every lane at the lane's own entry position (Tn), and a lane adopts it
+        // when its sample crosses (a control period holds at least two steps: launch_tube_oct).  Each exponential is
+        // evaluated in one of a voice's four slots of the block and handed to the other three.
+        OscSlotTrack T, Tn;
         double P = 0.0;                                 // oscillator position at the start of the step
-        float prev[4], cur[4], nxt[4];
-        uint32_t per = 0, j = (uint32_t)slot;           // control period / position in it of this lane's sample
+        float cur[4], nxt[4];                           // frames perN, perN + 1: the period after the one last set up runs between them
+        uint32_t perN = 1, bnd = CP;                    // bnd: first sample of that period
+        uint32_t j = (uint32_t)slot;                    // position of this lane's sample in its control period
+        auto setup_track = [&](OscSlotTrack &D, const float *fa, const float *fb, int jEntry) {
+            double x[4], e[4];
+            osc_slot_exp_args(C, fa, fb, x);
+            const double mine = exp2_d(part == 0 ? x[0] : part == 1 ? x[1] : part == 2 ? x[2] : x[3]);
+            e[0] = q_take<3, kPart3>(q_take<2, kPart2>(q_take<1, kPart1>(mine, mine), mine), mine);     // slot 0's, in every slot
+            e[1] = q_take<3, kPart0>(q_take<2, kPart3>(q_take<1, kPart2>(mine, mine), mine), mine);     // slot 1's
+            e[2] = q_take<3, kPart1>(q_take<2, kPart0>(q_take<1, kPart3>(mine, mine), mine), mine);     // slot 2's
+            e[3] = q_take<3, kPart2>(q_take<2, kPart1>(q_take<1, kPart0>(mine, mine), mine), mine);     // slot 3's
+            osc_slot_from_exps<3>(D, C, fa, fb, jEntry, e);
+        };
         if (nSteps > 0) {
-            load_frame(frames, frame_index(0), prev, 1);
+            float first[4];
+            load_frame(frames, frame_index(0), first, 1);
             load_frame(frames, frame_index(1), cur, 1);
             load_frame(frames, frame_index(2), nxt, 1);
-            osc_slot_setup_pow2<3>(T, C, prev, cur, (int)j);
+            setup_track(T, first, cur, (int)j);
         }
+        Tn = T;
         float2 *const ring = &sO[vq * kOStride];
         ScanState Z;
         scans_reset(Z);
@@ -245,12 +263,17 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                 thr = throat_scan(Z, thr);
             }
             if (step * kOB < nTotal) {
-                if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
+                if (step * kOB + (kOB - 1) >= bnd) {        // (uniform) a lane enters the period that starts at sample bnd (:289)
+                    const uint32_t ns = step * kOB + (uint32_t)slot;
+                    setup_track(Tn, cur, nxt, (int)(ns >= bnd ? ns - bnd : ns + kOB - bnd));
+                    for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+                    perN++;
+                    load_frame(frames, frame_index(perN + 1), nxt, 1);     // (used one period from now)
+                    bnd += CP;
+                }
+                if (j >= CP) {      // this lane's sample starts a control period
                     j -= CP;
-                    per++;
-                    for (int q = 0; q < 4; q++) { prev[q] = cur[q]; cur[q] = nxt[q]; }
-                    load_frame(frames, frame_index(per + 2), nxt, 1);
-                    osc_slot_setup_pow2<3>(T, C, prev, cur, (int)j);
+                    T = Tn;
                 }
                 const double db = __builtin_fma((double)j, T.glotDelta, T.glot0);
                 double axd = db >= 60.0 ? 1.0 : T.axGeo;      // amplitude() with its clamps (:294-296)
@@ -384,13 +407,14 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         ScanState Z;
         scans_reset(Z);
         CoefTrack T;
-        float prev[16], cur[16], nxt[16];
+        float cur[16], nxt[16];             // frames per + 1, per + 2 (the period's first frame lives on in T.base)
         uint32_t per = 0, j = (uint32_t)slot;
         if (nSteps > 0) {
-            load_frame(frames, frame_index(0), prev, 4);
+            float first[16];
+            load_frame(frames, frame_index(0), first, 4);
             load_frame(frames, frame_index(1), cur, 4);
             load_frame(frames, frame_index(2), nxt, 4);
-            coef_track_setup(T, C, prev, cur);
+            coef_track_setup(T, C, first, cur);
         }
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
@@ -400,9 +424,9 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                 if (j >= CP) {
                     j -= CP;
                     per++;
-                    for (int q = 0; q < 16; q++) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+                    coef_track_setup(T, C, cur, nxt);
+                    for (int q = 0; q < 16; q++) cur[q] = nxt[q];
                     load_frame(frames, frame_index(per + 2), nxt, 4);
-                    coef_track_setup(T, C, prev, cur);
                 }
                 Coefs K;
                 // [buf][slot][part p][voice]{k.x, k.y | in.x, in.y}: the area wave writes the k halves (and the mouth
@@ -680,7 +704,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
 hipError_t launch_tube_oct(const Const &c, const TubeArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
-    if (a.stream_state || c.controlPeriod < kOB) return hipErrorInvalidValue;     // (the caller picks trm_quad.hip's kernel for these)
+    if (a.stream_state || c.controlPeriod < 2 * kOB) return hipErrorInvalidValue;     // (the caller picks trm_quad.hip's kernel for these)
     // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
     static bool allowed[16] = {};
     int dev = 0;

@@ -278,16 +278,24 @@ struct OscSlotTrack {
 
 // `j` = the lane's position in the new control period, 0 <= j < 2^kLog2Slots; the lane's tracks then advance
 // 2^kLog2Slots samples at a time (four: trm_quad.hip; eight: trm_oct.hip).
-template <int kLog2Slots>
-TRM_HD void osc_slot_setup_pow2(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j)
+// The set-up's four exponentials (frequency(), TRMUtility.m:44-47; amplitude(), :26-41) are 2^x of these arguments:
+// {pitch at the period's start, pitch step per sample, glottal volume at the start, its step per sample}
+TRM_HD void osc_slot_exp_args(const Const &C, const float *prev, const float *cur, double x[4])
 {
     const double kLog2_10_over_20 = 0.16609640474436813;
-    double p0 = (double)prev[0], dp = ((double)cur[0] - p0) * C.invControlPeriodD;
-    double f0 = 220.0 * exp2_d((p0 + 3.0) * (1.0 / 12.0));
-    double r = exp2_d(dp * (1.0 / 12.0));
-    double v0 = (double)prev[1], dv = ((double)cur[1] - v0) / (double)C.controlPeriod;
-    double ax = exp2_d((v0 - 60.0) * kLog2_10_over_20);
-    double q = exp2_d(dv * kLog2_10_over_20);
+    const double p0 = (double)prev[0], dp = ((double)cur[0] - p0) * C.invControlPeriodD;
+    const double v0 = (double)prev[1], dv = ((double)cur[1] - v0) / (double)C.controlPeriod;
+    x[0] = (p0 + 3.0) * (1.0 / 12.0);
+    x[1] = dp * (1.0 / 12.0);
+    x[2] = (v0 - 60.0) * kLog2_10_over_20;
+    x[3] = dv * kLog2_10_over_20;
+}
+// ... and the track from their values e[k] = 2^x[k]
+template <int kLog2Slots>
+TRM_HD void osc_slot_from_exps(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j, const double e[4])
+{
+    const double v0 = (double)prev[1], dv = ((double)cur[1] - v0) / (double)C.controlPeriod;
+    double f0 = 220.0 * e[0], r = e[1], ax = e[2], q = e[3];
     // r^j, q^j by the bits of j; r^(2^kLog2Slots) is what is left in r
     double rj = 1.0, qj = 1.0;
     for (int b = 0; b < kLog2Slots; b++) {
@@ -304,6 +312,14 @@ TRM_HD void osc_slot_setup_pow2(OscSlotTrack &T, const Const &C, const float *pr
     T.glotDelta = dv;
     T.aspBase = prev[2];
     T.aspDelta = (cur[2] - prev[2]) * C.invControlPeriod;
+}
+template <int kLog2Slots>
+TRM_HD void osc_slot_setup_pow2(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j)
+{
+    double x[4], e[4];
+    osc_slot_exp_args(C, prev, cur, x);
+    for (int k = 0; k < 4; k++) e[k] = exp2_d(x[k]);
+    osc_slot_from_exps<kLog2Slots>(T, C, prev, cur, j, e);
 }
 TRM_HD void osc_slot_setup(OscSlotTrack &T, const Const &C, const float *prev, const float *cur, int j)
 {

@@ -331,7 +331,7 @@ int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_
  *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: mid-size batches (AUTO: above 16 voices per CU)
  *                    and every stream (trm_stream_*);
  *   TRM_KERNEL_OCT   eight lanes per voice, 8 voices per workgroup, two workgroups per CU: lowest latency for
- *                    batches of up to 16 voices per CU (4096 on MI355X).  Needs a control period of at least 8 tube
+ *                    batches of up to 16 voices per CU (4096 on MI355X).  Needs a control period of at least 16 tube
  *                    samples; where it does not apply (longer batches, shorter periods) TRM_KERNEL_QUAD runs instead.
  * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad|oct
  * overrides AUTO (diagnostics).  Parameters with more than four output samples per tube sample (96 kHz output)
