@@ -9,7 +9,7 @@
 //                          (rows of 16 lanes = 4 slots x 4 voices, exactly trm_quad.hip's layout), lanes 32-63 its second
 //                          block.  The recurrences that run over slots -- oscillator phase (a prefix sum), throat low-pass
 //                          and frication band-pass (serial scans) -- cross the halves with v_permlane32_swap.
-//   tube                   lanes = 8 parts of the tube (trm_oct.h): ~36 instructions per sample instead of 50
+//   tube                   lanes = 8 parts of the tube (trm_oct.h): ~35 instructions per sample instead of 50
 //   convert                lane = output time (rows of 32 outputs x 2 voices), two row pairs per block
 // One barrier per step of 8 tube samples.  At step i osc works on block i, mix on i-1, the coefficient waves and the two
 // scans on i-2, tube on i-4, convert on whatever is complete, metered.  No streaming instance (trm_quad.hip carries streams).
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     for (int i = threadIdx.x; i < kOV * kYStride; i += kThreads) sY[i] = 0.0f;
     for (int i = threadIdx.x; i < kOV * kOStride; i += kThreads) sO[i] = make_float2(0.0f, 0.0f);
     for (int i = threadIdx.x; i < kKDepth * kOB * kOKRow; i += kThreads) sK[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = threadIdx.x; i < 4 * kOXArray; i += kThreads) sX[i] = 0.0f;
     if (threadIdx.x < 2) sRowSync[threadIdx.x] = 0u;
     __syncthreads();
     // what no wave writes per sample: the nasal tract's constant records (parts 6, 7; part 5's injections stay 0)

@@ -194,6 +194,41 @@ def test_very_high_rate_ratio_runs_the_lane_form(g, form):
         g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=1)
 
 
+def test_eight_lane_form_runs_where_it_applies(g, monkeypatch):
+    """TRM_KERNEL_OCT (include/trm_c_api.h): AUTO's choice for batches of up to two 8-voice workgroups per CU; a control
+    period below 16 tube samples (its feed-forward lanes step 8 samples at a time and set a period up while the lanes of
+    the one before still cross into it) or a longer batch runs the four-lane form instead, whatever was asked for -- with
+    the same result against the oracle."""
+    monkeypatch.delenv("TRM_TUBE_KERNEL", raising=False)
+    monkeypatch.delenv("TRM_QUAD_CUS", raising=False)
+    rows = cases.load_gnuspeech_rows()
+    voices = [rows[:90].copy(), rows[40:200].copy(), rows[5:7].copy()]
+    pd = cases.monet_default_params(44100.0)
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    b.synthesize(voices)
+    assert b.last_kernel == "oct"                       # AUTO, small batch
+    pd["controlRate"] = 1000.0
+    pd["length"] = 30.0                                 # control period 12 tube samples
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    assert b.derived["controlPeriod"] < 16
+    b.set_kernel("oct")
+    b.synthesize(voices)
+    assert b.last_kernel == "quad"
+    _batch_vs_oracle(g, pd, voices)
+    pd["length"] = 20.0                                 # control period 18: two steps fit
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    assert 16 <= b.derived["controlPeriod"] < 24
+    b.synthesize(voices)
+    assert b.last_kernel == "oct"
+    _batch_vs_oracle(g, pd, voices)
+    monkeypatch.setenv("TRM_QUAD_CUS", "1")             # (read at create: a "device" of one CU holds 16 voices in this form)
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params(44100.0)))
+    b.synthesize([rows[:30].copy()] * 16)
+    assert b.last_kernel == "oct"
+    b.synthesize([rows[:30].copy()] * 17)
+    assert b.last_kernel == "quad"
+
+
 def test_extreme_rate_ratios(g, form):
     """Converter ratios at both ends of the up-sampling range: a 30 cm tube (tube rate ~11.7 kHz, ratio 3.8 at
     44.1 kHz: the converter produces ~15 outputs per pipeline step) and a 15.8 cm tube at 22.05 kHz (ratio 1.008)."""
