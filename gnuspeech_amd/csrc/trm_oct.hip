@@ -27,6 +27,7 @@
 #undef TRM_OCT_ROLE_PERM
 #undef TRM_OCT_TUBE_PRIO
 #undef TRM_ABL_SKIP
+#undef TRM_ISA_ROLE
 #endif
 
 namespace trm {
@@ -110,6 +111,9 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     const int rolePerm[kORoles] = {TRM_OCT_ROLE_PERM};
     int role = 0;
     for (int i = 0; i < kORoles; i++) role = waveIdx == i ? rolePerm[i] : role;
+#ifdef TRM_ISA_ROLE      // instruction-count studies (tools/isa_mix.py role N): every wave is this role, the other bodies fold away
+    role = TRM_ISA_ROLE;
+#endif
 
     // feed-forward waves: lane -> (voice, slot); a row of 16 lanes = 4 banks (slot within the block) x 4 voices, lanes
     // 0-31 the step's first block, 32-63 its second.  Tube wave: lane -> (voice, part), 8 consecutive lanes per voice.
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
             // block i-2: the mix wave's {sig, thr} were written during step i-1; the tube wave reads the result from step i+1 on
+            // (the scan in the mix wave instead -- the lighter role by instruction count -- measured 2.5 % slower)
             if (step >= 2 && (step - 2) * kOB < nTotal) {
                 float &thr = x_at(kXThr, step - 2, slot);
                 thr = throat_scan(Z, thr);
@@ -388,10 +393,9 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
                 const float pulse = acc0.x + acc0.y;
                 const float2 a = sA[((step - 1) & 1u) * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
-                // (thr raw: the oscillator wave turns it into the throat output one step on)
                 x_at(kXGin, step - 1, slot) = E.gin;
                 x_at(kXSig, step - 1, slot) = E.sig;
-                x_at(kXThr, step - 1, slot) = E.thr;
+                x_at(kXThr, step - 1, slot) = E.thr;       // (raw: the oscillator wave turns it into the throat output one step on)
             }
             STAMP_MID
             step_barrier();
