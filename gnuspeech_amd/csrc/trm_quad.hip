@@ -368,21 +368,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 // 26-sample window starting at the even index m - 24 - o (zeros before the first sample)
                 const uint32_t s0 = (m + kORing - 24u - (uint32_t)o) & (kORing - 1);
                 const float4 *wp = reinterpret_cast<const float4 *>(&ring[s0]);
-                // fir_direct's four partial sums as two packed ones: even / odd window slots x (a, b)
-                v2f acc0, acc1;
-                {
-                    const float4 x = wp[0];
-                    acc0 = v2f{x.x, x.y} * cab[0];
-                    acc1 = v2f{x.z, x.w} * cab[1];
-                }
-#pragma unroll
-                for (int q = 1; q < kFirWin / 2; q++) {
-                    const float4 x = wp[q];
-                    acc0 = __builtin_elementwise_fma(v2f{x.x, x.y}, cab[2 * q], acc0);
-                    acc1 = __builtin_elementwise_fma(v2f{x.z, x.w}, cab[2 * q + 1], acc1);
-                }
-                acc0 += acc1;
-                const float pulse = acc0.x + acc0.y;
+                const float pulse = fir_window_dot(wp, cab);
                 const float2 a = sA[buf * kWave + lane];
                 const Excitation E = mix_tail(C, a.x, a.y, pulse, sNoise[m & (kNoiseRing - 1)]);
 #if TRM_THROAT_IN_OSC
@@ -624,42 +610,8 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             const float4 *wa = reinterpret_cast<const float4 *>(&sY[(la + ha) * kYStride + winBase]);
             const float4 *wb = reinterpret_cast<const float4 *>(&sY[(lb + ha) * kYStride + winBase]);
             const uint4 ia = sInfo[la + ha], ib = sInfo[lb + ha];
-            // 32-term dot products as packed FMAs: (even, odd) partial sums, two chains per row; the second
-            // row's window is read while the first row's chains run (one row's registers are live at a time)
-            v2f a0, a1, b0, b1;
-            {
-                float4 q[8];
-#if TRM_ABL_CVT == 2      /* (timing experiments: 2 = one ring read per row instead of eight) */
-                q[0] = wa[0];
-                for (int i = 1; i < 8; i++) q[i] = make_float4(q[0].y, q[0].z, q[0].w, q[0].x + (float)i);
-#else
-                for (int i = 0; i < 8; i++) q[i] = wa[i];
-#endif
-                a0 = v2f{q[0].x, q[0].y} * cc[0];
-                a1 = v2f{q[0].z, q[0].w} * cc[1];
-                for (int i = 1; i < 8; i++) {
-                    a0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], a0);
-                    a1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], a1);
-                }
-            }
-            {
-                float4 q[8];
-#if TRM_ABL_CVT == 2
-                q[0] = wb[0];
-                for (int i = 1; i < 8; i++) q[i] = make_float4(q[0].y, q[0].z, q[0].w, q[0].x + (float)i);
-#else
-                for (int i = 0; i < 8; i++) q[i] = wb[i];
-#endif
-                b0 = v2f{q[0].x, q[0].y} * cc[0];
-                b1 = v2f{q[0].z, q[0].w} * cc[1];
-                for (int i = 1; i < 8; i++) {
-                    b0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], b0);
-                    b1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], b1);
-                }
-            }
-            a0 += a1;
-            b0 += b1;
-            const float ya = a0.x + a0.y, yb = b0.x + b0.y;
+            // (the second row's window is read while the first row's chains run: one row's registers are live at a time)
+            const float ya = cvt_window_dot(wa, cc), yb = cvt_window_dot(wb, cc);
             const bool okA = kLane < ia.x, okB = kLane < ib.x;
 #if TRM_ABL_CVT != 1      /* (timing experiments: 1 = no PCM stores) */
             if (okA) reinterpret_cast<GlobalFloatPtr>(((uintptr_t)ia.z << 32) | ia.y)[kLane] = ya;

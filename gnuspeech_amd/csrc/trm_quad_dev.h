@@ -8,6 +8,7 @@
 
 #include "trm_devutil.h"
 #include "trm_lane.h"
+#include "trm_quad.h"
 
 namespace trm {
 
@@ -38,5 +39,42 @@ constexpr int kRowBufs = 3;          // converter coefficient rows staged in LDS
 constexpr int kRowPitch = kSrcRowC + 4;  // staged coefficient rows: 144 bytes apart, so that 16 lanes reading 16 rows hit 16 bank groups
 constexpr int kQLead = 28;           // tube sample n sits at converter-ring slot (n + 28) & 127: the converter's 25 zeros of
                                      // pre-roll (TRMSampleRateConverter.m:138-150) + 3, so that a block of 4 is 16-byte aligned
+
+// The oscillator FIR of one tube sample in direct form (fir_direct, trm_quad.h) over the LDS ring of oscillator reads: the
+// 26-sample window as 13 aligned 16-byte reads of (a, b) pairs, fir_direct's four partial sums as two packed ones
+// (even / odd window slots x (a, b)); `cab` = the window taps of the sample's parity as (a, b) pairs.
+__device__ __forceinline__ float fir_window_dot(const float4 *wp, const v2f *cab)
+{
+    v2f acc0, acc1;
+    {
+        const float4 x = wp[0];
+        acc0 = v2f{x.x, x.y} * cab[0];
+        acc1 = v2f{x.z, x.w} * cab[1];
+    }
+#pragma unroll
+    for (int q = 1; q < kFirWin / 2; q++) {
+        const float4 x = wp[q];
+        acc0 = __builtin_elementwise_fma(v2f{x.x, x.y}, cab[2 * q], acc0);
+        acc1 = __builtin_elementwise_fma(v2f{x.z, x.w}, cab[2 * q + 1], acc1);
+    }
+    acc0 += acc1;
+    return acc0.x + acc0.y;
+}
+
+// One converter output (src_dot32, trm_lane.h): the 32-term dot product of a 16-byte aligned window of the tube-rate ring
+// with the phase's shifted coefficient row, as packed FMAs: (even, odd) partial sums, two chains.
+__device__ __forceinline__ float cvt_window_dot(const float4 *w, const v2f *cc)
+{
+    float4 q[8];
+    for (int i = 0; i < 8; i++) q[i] = w[i];
+    v2f a0 = v2f{q[0].x, q[0].y} * cc[0];
+    v2f a1 = v2f{q[0].z, q[0].w} * cc[1];
+    for (int i = 1; i < 8; i++) {
+        a0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], a0);
+        a1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], a1);
+    }
+    a0 += a1;
+    return a0.x + a0.y;
+}
 
 }  // namespace trm
