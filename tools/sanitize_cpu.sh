@@ -19,7 +19,7 @@ for f in trm_capi trm_setup trm_io; do
     hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-sanitize-recover=undefined -c $f.cc -o $T/$f.o
 done
 hipcc --offload-arch=gfx950 -shared -fsanitize=address,undefined -o $T/libtrm_hip_san.so $T/trm_capi.o $T/trm_setup.o $T/trm_io.o \
-    build/trm_kernels.o build/trm_quad.o build/trm_tracks.o
+    build/trm_kernels.o build/trm_quad.o build/trm_oct.o build/trm_tracks.o
 cd ../..
 echo "== library host code under clang ASan+UBSan"
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
