@@ -115,8 +115,8 @@ def cpu_baseline(pd, frames, wall_s=3.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)        # (a step is 2.5 ms: the default run is the CPU baseline's 3 s + 65 ms)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default: 4096 at --gpus 1 = configs[1]; 8192 at --gpus N = configs[4])")
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--workload", default=None, choices=["static", "timevarying"],
