@@ -10,6 +10,13 @@ A "step" = one pass of -[TRMTubeModel synthesize] over one resident batch of syn
                       barrier and the MAX-over-ranks time.  When the ranks are not there yet (no WORLD_SIZE in the
                       environment), this process starts them as a CHILD `python -m torch.distributed.run` before it
                       touches the GPU and relays rank 0's line.
+  --config K          the per-GPU workload by BASELINE.json configs[] index, whatever --gpus says: 1 = 4096 static
+                      tubes, 2 = 4096 time-varying tubes, 4 = ONE GPU's shard of configs[4] (8192 time-varying voices).
+                      `--gpus 1 --config 4` is the single-GPU run an N-rank line compares with (its `scaling_baseline`).
+
+The N-rank line is self-contained for weak scaling: besides the contract's MAX-over-ranks time it carries every rank's
+own elapsed and kernel time (`per_rank_ms`, `per_rank_kernel_ms`, gathered after the timed region), `per_gpu_value`, and
+`solo_ms_per_step` = rank 0 running the same shard ALONE (the other ranks idle at a barrier; outside the timed region).
 
 Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).
 """
@@ -108,23 +115,69 @@ def cpu_baseline(pd, frames, wall_s=3.0):
             "per_core": float(sum(res)) / dt / cores,
             "host_hardware_threads": os.cpu_count(),
             "sample": "%d voice runs (the workload's %d voices cyclically, %d output samples each) = %.0f s of CPU work in "
-                      "%.2f s on %d threads (the cores this job may use), oracle/trm_oracle.c (double), one voice per task"
-                      % (cores * per_thread, nv, per_voice_samples, dt * cores, dt, cores)}
+                      "%.2f s on %d threads (the cores this job may use: %d of the host's %d hardware threads), "
+                      "oracle/trm_oracle.c (double), one voice per task"
+                      % (cores * per_thread, nv, per_voice_samples, dt * cores, dt, cores, cores, os.cpu_count() or cores)}
 
 
-def main():
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")
+CONFIGS = {1: (4096, "static"), 2: (4096, "timevarying"), 4: (8192, "timevarying")}     # BASELINE.json configs[K] per GPU
+
+
+def lookup_traffic(voices, nframes, kind, form, avg_launch_s):
+    """HBM bytes and VALU instructions per launch come from separate rocprofv3 --pmc passes (they cannot be combined
+    with the timed run).  profiles/traffic_r03.json holds one entry per (workload, kernel form) that was profiled
+    (tools/profile_workload.sh + tools/make_traffic.py), the whole file stamped with kernel_source_hash(): an entry is
+    only quoted for THIS workload in THIS kernel form built from THESE kernel sources; otherwise traffic is null."""
+    try:
+        tj = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None, "no PMC profile (profiles/traffic_r03.json missing)"
+    if tj.get("kernel_source_sha16") != kernel_source_hash():
+        return None, None, "profiles/traffic_r03.json is stale (kernel sources changed since the PMC passes): not quoted"
+    for e in tj.get("entries", []):
+        w = e.get("workload", {})
+        if (w.get("voices_per_gpu"), w.get("frames_per_voice"), w.get("kind"), w.get("kernel_form")) != (voices, nframes, kind, form):
+            continue
+        valu = None
+        if e.get("SQ_INSTS_VALU") and e.get("issue_cycles_per_valu"):
+            # wave64 VALU instructions of one launch (PMC) x the mix-weighted issue cost measured by tools/ubench
+            # against this run's launch time on 1024 SIMDs at the 2.4 GHz peak clock
+            valu = {"insts_per_launch": e["SQ_INSTS_VALU"], "issue_cycles_per_inst": e["issue_cycles_per_valu"],
+                    "source": e["source"] + "; " + e.get("issue_cycles_source", ""),
+                    "frac_of_issue_slots": e["SQ_INSTS_VALU"] * e["issue_cycles_per_valu"] / (avg_launch_s * 2.4e9 * 1024)}
+        return e["traffic_bytes_per_launch"], valu, e["source"]
+    return None, None, "no PMC profile for this workload / kernel form in profiles/traffic_r03.json"
+
+
+def resolve_workload(a, world):
+    """(configs[] index, voices per GPU, kind) of a run: --config names the per-GPU workload, --voices / --workload
+    override its parts; without --config: configs[1] on one GPU, configs[4]'s shard per GPU on several."""
+    config = a.config if a.config is not None else (4 if world > 1 else 1)
+    voices = a.voices if a.voices is not None else CONFIGS[config][0]
+    kind = a.workload if a.workload is not None else CONFIGS[config][1]
+    return config, voices, kind
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)        # (a step is 2.5 ms: the default run is the CPU baseline's 3 s + 65 ms)
+    ap.add_argument("--steps", type=int, default=200)       # (a step is ~2.5 ms: half a second of GPU work after the CPU baseline's 3 s)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--voices", type=int, default=None, help="voices per GPU (default: 4096 at --gpus 1 = configs[1]; 8192 at --gpus N = configs[4])")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="per-GPU workload = BASELINE.json configs[K] (4: one GPU's shard of it); default 1 at --gpus 1, 4 at --gpus N")
+    ap.add_argument("--voices", type=int, default=None, help="voices per GPU (overrides --config's)")
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--workload", default=None, choices=["static", "timevarying"],
-                    help="default: static at --gpus 1 (configs[1]), timevarying at --gpus N (configs[4]: config-3 voices)")
+                    help="overrides --config's: static (config-2 voices) or timevarying (config-3 voices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "quad", "oct"],
                     help="kernel form (include/trm_c_api.h); auto = the library's choice by batch size")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         # No ranks yet: start them as a child process (never re-exec a process that may have touched the GPU -- this one
@@ -143,8 +196,7 @@ def main():
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world))
     dist = world > 1
-    voices = a.voices if a.voices is not None else (8192 if dist else 4096)
-    workload = a.workload if a.workload is not None else ("timevarying" if dist else "static")
+    config, voices, workload = resolve_workload(a, world)
 
     import numpy as np
     import cases
@@ -159,6 +211,8 @@ def main():
         wname = "configs[2]: batch=%d time-varying tubes (gnuspeech.input tracks) x %.3g s @ 44.1 kHz" % (voices, a.seconds)
     if dist:
         wname = "configs[4]: %d utterances sharded %d per GPU over %d GPUs (no collective); per GPU = %s" % (voices * world, voices, world, wname)
+    elif config == 4 and a.voices is None and a.workload is None:
+        wname = "configs[4], ONE GPU's shard: %d of 65536 utterances (what every rank of --gpus 8 runs); = %s" % (voices, wname)
 
     # the CPU leg first: before this process has a GPU context (rank 0 at N=1 only)
     cpu = None
@@ -188,6 +242,18 @@ def main():
     for _ in range(a.warmup):
         b.synthesize_device(st, stream)
     torch.cuda.synchronize()
+    solo_ms = None
+    if dist:
+        # outside the timed region: rank 0 runs its shard ALONE while the others wait -- what a reader needs to turn the
+        # timed region below into a weak-scaling efficiency without a second run
+        td.barrier()
+        if rank == 0:
+            ks = max(1, min(a.steps, 50))
+            t0 = time.perf_counter()
+            for _ in range(ks):
+                b.synthesize_device(st, stream)
+            torch.cuda.synchronize()
+            solo_ms = (time.perf_counter() - t0) / ks * 1e3
     b.kernel_time_ms()                                     # reset the per-launch event accumulator
     if dist:
         td.barrier()
@@ -196,15 +262,24 @@ def main():
     for _ in range(a.steps):
         b.synthesize_device(st, stream)
     torch.cuda.synchronize()
+    own_dt = time.perf_counter() - t0                      # this rank's own launches + sync, before the closing barrier
     if dist:
         td.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kern_ms, launches = b.kernel_time_ms()                 # hipEvents on the launch stream
+    per_rank_ms = per_rank_kernel_ms = None
     if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dev = "cpu" if rehearsal else "cuda"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         dt = float(tmax.item())
-    kern_ms, launches = b.kernel_time_ms()                 # hipEvents on the launch stream
+        # every rank's own numbers, gathered after the timed region: [elapsed incl. the closing barrier, kernel time]
+        mine = torch.tensor([own_dt * 1e3 / a.steps, kern_ms / max(1, launches)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(allr, mine)
+        per_rank_ms = [float(x[0]) for x in allr]
+        per_rank_kernel_ms = [float(x[1]) for x in allr]
 
     samples_per_step_rank = int(st["total_out"])
     total_samples = samples_per_step_rank * a.steps * world
@@ -214,28 +289,7 @@ def main():
     alg_bytes = 4.0 * samples_per_step_rank + 64.0 * voices * nframes
     avg_launch_s = (kern_ms / max(1, launches)) * 1e-3
     achieved = alg_bytes / avg_launch_s / 1e9
-    # HBM bytes per launch come from separate rocprofv3 --pmc passes (they cannot be combined with the timed run);
-    # the committed file is only quoted when it was collected on THIS workload with THESE kernel sources
-    # (tools/make_traffic.py stamps it with kernel_source_hash()), otherwise traffic is null
-    traffic = None
-    valu = None
-    traffic_note = "no PMC profile for this workload"
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
-        w = tj["workload"]
-        if tj.get("kernel_source_sha16") != kernel_source_hash():
-            traffic_note = "profiles/traffic_r02.json is stale (kernel sources changed since the PMC pass): not quoted"
-        elif (w["voices_per_gpu"], w["frames_per_voice"], w["kind"], w["kernel_form"]) == (voices, nframes, workload, b.last_kernel):
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_note = tj["source"]
-            if "SQ_INSTS_VALU" in tj and "issue_cycles_per_valu" in tj:
-                # wave64 VALU instructions of one launch (PMC) x the mix-weighted issue cost measured by tools/ubench
-                # (profiles/valu_ceiling_r02.txt) against this run's launch time on 1024 SIMDs at the 2.4 GHz peak clock
-                valu = {"insts_per_launch": tj["SQ_INSTS_VALU"], "issue_cycles_per_inst": tj["issue_cycles_per_valu"],
-                        "source": tj["source"] + "; " + tj.get("issue_cycles_source", ""),
-                        "frac_of_issue_slots": tj["SQ_INSTS_VALU"] * tj["issue_cycles_per_valu"] / (avg_launch_s * 2.4e9 * 1024)}
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, valu, traffic_note = lookup_traffic(voices, nframes, workload, b.last_kernel, avg_launch_s)
     out = {
         "metric": "audio samples/s (whole node) + concurrent real-time tube voices",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -253,6 +307,14 @@ def main():
                      "note": "VALU-issue bound scalar recurrence (SURVEY 8d); HBM-write fraction reported as BASELINE asks"},
         "cpu_baseline": cpu,
     }
+    if dist:
+        out["per_rank_ms"] = per_rank_ms                   # ms per step, every rank's own clock (launches + device sync)
+        out["per_rank_kernel_ms"] = per_rank_kernel_ms     # average tube-kernel launch per rank (hipEvents)
+        out["per_gpu_value"] = [samples_per_step_rank / (t * 1e-3) for t in per_rank_ms]
+        out["solo_ms_per_step"] = solo_ms                  # rank 0 alone on the same shard, outside the timed region
+        out["weak_scaling_efficiency_in_run"] = (solo_ms / (dt / a.steps * 1e3)) if solo_ms else None
+        out["scaling_baseline"] = ("python bench.py --gpus 1 --voices %d --workload %s --seconds %g: the same per-GPU shard on one "
+                                   "GPU (--gpus 1 WITHOUT these flags is configs[1], another workload)" % (voices, workload, a.seconds))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

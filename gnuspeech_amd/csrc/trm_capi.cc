@@ -528,6 +528,7 @@ struct trm_stream {
     std::vector<float> hostFrames, hostOut;
     bool haveLast = false;            // an utterance is open
     bool first = true;                // no chunk of it has been synthesized yet
+    int mode = TRM_STREAM_MODE_FRAMEWORK;
     uint64_t nBase = 0, kBase = 0;    // tube samples synthesized / converter outputs emitted so far
 };
 
@@ -585,10 +586,22 @@ static uint64_t outputs_through(uint64_t lastSamplePlusOne, uint32_t inc)
     return ((lastSamplePlusOne << 16) - 1) / inc + 1;
 }
 
+int trm_stream_set_mode(trm_stream *s, int mode)
+{
+    if (!s) return fail(TRM_EINVAL, "null stream");
+    if (mode != TRM_STREAM_MODE_FRAMEWORK && mode != TRM_STREAM_MODE_TRACT) return fail(TRM_EINVAL, "unknown stream mode %d", mode);
+    if (s->haveLast) return fail(TRM_EINVAL, "the stream's mode can only change between utterances (before the first push or after finish)");
+    s->mode = mode;
+    s->b->c.fricGain = mode == TRM_STREAM_MODE_TRACT ? 10.0f : 1.0f;      // Applications/TRAcT/tube.c:1371
+    return TRM_OK;
+}
+
+int trm_stream_mode(const trm_stream *s) { return s ? s->mode : TRM_STREAM_MODE_FRAMEWORK; }
+
 size_t trm_stream_samples_for_push(const trm_stream *s, size_t nframes)
 {
     if (!s || nframes == 0) return 0;
-    const uint64_t periods = s->haveLast ? nframes : nframes - 1;
+    const uint64_t periods = (s->haveLast || s->mode == TRM_STREAM_MODE_TRACT) ? nframes : nframes - 1;
     const uint64_t N = periods * (uint64_t)s->b->d.controlPeriod;
     return (size_t)(outputs_through(s->nBase + N, s->b->c.timeRegisterIncrement) - s->kBase);
 }
@@ -608,7 +621,11 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
     trm_batch *b = s->b;
     const size_t V = s->nvoices;
     const uint32_t CP = (uint32_t)b->d.controlPeriod, inc = b->c.timeRegisterIncrement;
-    const size_t rows = (flush ? 0 : nframes) + (s->haveLast ? 1 : 0);        // frame rows per voice on the device
+    const bool tract = s->mode == TRM_STREAM_MODE_TRACT;
+    // TRAcT order: every frame is one control period of HELD parameters, the utterance's first one included; the kernel
+    // runs period p on row p + 1 alone (stream_flags bit 2), so row 0 only has to exist
+    const bool leadRow = s->haveLast || (tract && !flush);
+    const size_t rows = (flush ? 0 : nframes) + (leadRow ? 1 : 0);            // frame rows per voice on the device
     if (rows == 0) { if (nout) *nout = 0; return TRM_OK; }
     const uint64_t N = (uint64_t)(rows - 1) * CP;
     const uint64_t kEnd = flush ? ((s->nBase + 2ull * (uint64_t)b->d.padSize) * 65536ull + inc - 1) / inc
@@ -630,7 +647,7 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
     for (size_t v = 0; v < V; v++) {
         float *dst = &s->hostFrames[v * rows * 16];
         size_t r = 0;
-        if (s->haveLast) { memcpy(dst, &s->lastFrame[v * 16], 16 * sizeof(float)); r = 1; }
+        if (leadRow) { memcpy(dst, s->haveLast ? &s->lastFrame[v * 16] : frames + v * nframes * 16, 16 * sizeof(float)); r = 1; }
         if (!flush) memcpy(dst + r * 16, frames + v * nframes * 16, nframes * 16 * sizeof(float));
         foff[v] = v * rows;
         ooff[v] = v * count;
@@ -672,7 +689,7 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         a.max_nframes = 0xFFFFFFFFu;          // (nframes is this function's own vector)
         a.stamps = nullptr;
             a.stream_state = s->dState.p;
-        a.stream_flags = (s->first ? 1u : 0u) | (flush ? 2u : 0u);
+        a.stream_flags = (s->first ? 1u : 0u) | (flush ? 2u : 0u) | (tract ? 4u : 0u);
         a.stream_n_base = (uint32_t)s->nBase;
         a.stream_k_base = (uint32_t)s->kBase;
         a.stream_k_end = (uint32_t)kEnd;
@@ -714,6 +731,12 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
     std::vector<float> mx(V, 0.0f);
     if (N > 0 || flush) HIP_TRY(hipMemcpyAsync(mx.data(), s->dMax.p, V * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (tract) {
+        // tube.c:1177 multiplies the tube-rate sample by 100 before its converter; the converter is linear, so the gain is
+        // applied to what it returns (one fp32 rounding of difference)
+        for (size_t i = 0; i < V * (size_t)count; i++) s->hostOut[i] *= 100.0f;
+        for (size_t v = 0; v < V; v++) mx[v] *= 100.0f;
+    }
     for (size_t v = 0; v < V && count > 0; v++) memcpy(out + v * out_pitch, &s->hostOut[v * (size_t)count], (size_t)count * sizeof(float));
     if (max_out) memcpy(max_out, mx.data(), V * sizeof(float));
     s->nBase += N;

@@ -4,7 +4,32 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <vector>
+
 namespace trm {
+
+// More than 64 KB of dynamic LDS has to be allowed once per kernel and device (hipFuncSetAttribute).  One of these per
+// kernel instance (a function-local static of its launcher): handles of different devices launch from different
+// threads, so the bookkeeping is locked, and it grows with the device index instead of capping it.
+struct DynamicLdsAllowance {
+    std::mutex m;
+    std::vector<char> done;
+    hipError_t ensure(const void *kernel, int bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(m);
+        if ((size_t)dev >= done.size()) done.resize((size_t)dev + 1, 0);
+        if (!done[dev]) {
+            e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+            done[dev] = 1;
+        }
+        return hipSuccess;
+    }
+};
 
 constexpr int kWave = 64;
 constexpr int kNoiseRing = 128;      // noise ring: one float per tube sample, refilled by halves of 64

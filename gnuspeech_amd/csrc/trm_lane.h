@@ -106,6 +106,7 @@ struct Const {
     float mA10, nA10;
     float ta0, tb1, throatGain;           // throat low-pass                 (TRMFilters.m:64-68)
     float invSampleRate;
+    float fricGain;             // 1 (:750); 10 in TRAcT's loop order (Applications/TRAcT/tube.c:1371, trm_stream_set_mode)
     // glottal pulse table geometry (TRMWavetable.m:71-75)
     int32_t tableDiv1, tableDiv2;
     float invDiv1;
@@ -379,6 +380,9 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
     K.ntd1 = v2 * (d2 * rcp_f(v2 + C.noseR1sq));
 }
 
+// kFricGain: multiply the frication amplitude by C.fricGain (the streaming kernel instance only: trm_stream_set_mode;
+// the one-shot instances carry no such instruction)
+template <bool kFricGain = false>
 TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j)
 {
     const float fj = (float)j;
@@ -392,6 +396,7 @@ TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j
     // select chain: three plain operations per tap.  Positions below 0 are outside the tract (the reference's split
     // is meaningless there as well).
     float fricAmp = amplitude_f(fricDb);
+    if (kFricGain) fricAmp *= C.fricGain;
     const float fricPos = fma_f(fj, T.fricPosDelta, T.fricPos0);                 // (:676-688)
     for (int i = 0; i < 8; i++) {
         const float dist = fabsf(fricPos - (float)i);
@@ -423,11 +428,12 @@ TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j
     K.pad_ = 0.0f;
 }
 
+template <bool kFricGain = false>
 TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
 {
     Coefs K;
     coef_sample_area(K, T, C, j);
-    coef_sample_fric(K, T, C, j);
+    coef_sample_fric<kFricGain>(K, T, C, j);
     return K;
 }
 

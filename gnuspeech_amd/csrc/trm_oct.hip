@@ -672,16 +672,9 @@ hipError_t launch_tube_oct(const Const &c, const TubeArgs &a, hipStream_t stream
 {
     if (a.nvoices == 0) return hipSuccess;
     if (a.stream_state || c.controlPeriod < 2 * kOB) return hipErrorInvalidValue;     // (the caller picks trm_quad.hip's kernel for these)
-    // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
-    static bool allowed[16] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static DynamicLdsAllowance lds;
+    hipError_t e = lds.ensure(reinterpret_cast<const void *>(trm_tube_kernel_o), (int)OctLds::kBytes);
     if (e != hipSuccess) return e;
-    if (dev < 16 && !allowed[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(trm_tube_kernel_o), hipFuncAttributeMaxDynamicSharedMemorySize, (int)OctLds::kBytes);
-        if (e != hipSuccess) return e;
-        allowed[dev] = true;
-    }
     const uint32_t grid = (a.nvoices + kOV - 1) / kOV;
     hipLaunchKernelGGL(trm_tube_kernel_o, dim3(grid), dim3(kWave * kORoles), OctLds::kBytes, stream, c, a);
     return hipGetLastError();

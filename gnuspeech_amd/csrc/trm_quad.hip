@@ -124,6 +124,9 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     // streaming: this launch is one chunk of a longer utterance (trm_kernels.h); one-shot = first and last at once
     constexpr bool streaming = kStream;
     const bool sFirst = !streaming || (A.stream_flags & 1u), sLast = !streaming || (A.stream_flags & 2u);
+    // TRAcT's loop (Applications/TRAcT/tube.c:1121-1136) reads the parameter set every sample and never interpolates: a
+    // control period then runs on the frame that ENDS it, held (trm_stream_set_mode)
+    const bool sHold = streaming && (A.stream_flags & 4u);
     const uint32_t nBase = streaming ? A.stream_n_base : 0u, kBase = streaming ? A.stream_k_base : 0u;
     float *const st = streaming ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
     // tube samples the tube stage produces: the utterance (chunk), then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93)
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             load_frame(frames, frame_index(0), prev, 1);
             load_frame(frames, frame_index(1), cur, 1);
             load_frame(frames, frame_index(2), nxt, 1);
+            if (sHold) for (int q = 0; q < 4; q++) prev[q] = cur[q];
             osc_slot_setup(T, C, prev, cur, (int)j);
         }
         float2 *const ring = &sO[vq * kOStride];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
                     j -= CP;
                     per++;
-                    for (int q = 0; q < 4; q++) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+                    for (int q = 0; q < 4; q++) { prev[q] = sHold ? nxt[q] : cur[q]; cur[q] = nxt[q]; }
                     load_frame(frames, frame_index(per + 2), nxt, 1);
                     osc_slot_setup(T, C, prev, cur, (int)j);
                 }
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             load_frame(frames, frame_index(0), prev, 4);
             load_frame(frames, frame_index(1), cur, 4);
             load_frame(frames, frame_index(2), nxt, 4);
+            if (sHold) for (int q = 0; q < 16; q++) prev[q] = cur[q];
             coef_track_setup(T, C, prev, cur);
         }
         STAMP_DECL
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 if (j >= CP) {
                     j -= CP;
                     per++;
-                    for (int q = 0; q < 16; q++) { prev[q] = cur[q]; cur[q] = nxt[q]; }
+                    for (int q = 0; q < 16; q++) { prev[q] = sHold ? nxt[q] : cur[q]; cur[q] = nxt[q]; }
                     load_frame(frames, frame_index(per + 2), nxt, 4);
                     coef_track_setup(T, C, prev, cur);
                 }
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                     for (int p = 0; p < 4; p++) dst[p * 4] = make_float4(R[p].kk[0], R[p].kk[1], R[p].kk[2], R[p].kk[3]);
                     sBP[(buf * kQB + part) * kXPitch + vq] = make_float4(H.endK[0], H.endK[1], H.endOnePlus[0], H.endOnePlus[1]);
                 } else {
-                    coef_sample_fric(K, T, C, (int)j);
+                    coef_sample_fric<kStream>(K, T, C, (int)j);
                     pack_part_tp(K, R);
                     pack_shared_bp(K, H);
                     const float f = bandpass_scan(Z, blk, make_float4(H.bpA2, H.bpB2, H.bpG2, 0.0f));
@@ -697,17 +702,9 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
 template <bool kStream, int kSub>
 static hipError_t launch_instance(const Const &c, const TubeArgs &a, hipStream_t stream, uint32_t grid)
 {
-    // more than 64 KB of dynamic LDS has to be allowed once per kernel and device
-    static bool allowed[16] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static DynamicLdsAllowance lds;
+    hipError_t e = lds.ensure(reinterpret_cast<const void *>(trm_tube_kernel_q<kStream, kSub>), (int)QuadLds<kSub>::kBytes);
     if (e != hipSuccess) return e;
-    if (dev < 16 && !allowed[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(trm_tube_kernel_q<kStream, kSub>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)QuadLds<kSub>::kBytes);
-        if (e != hipSuccess) return e;
-        allowed[dev] = true;
-    }
     hipLaunchKernelGGL((trm_tube_kernel_q<kStream, kSub>), dim3(grid), dim3(kWave * kQRoles), QuadLds<kSub>::kBytes, stream, c, a);
     return hipGetLastError();
 }

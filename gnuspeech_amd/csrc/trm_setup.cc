@@ -186,6 +186,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
         c.throatGain = (float)amplitude(p.throatVol);                    // :239
     }
     c.invSampleRate = (float)(1.0 / d.sampleRate);
+    c.fricGain = 1.0f;
     c.tableDiv1 = (int32_t)rint(512 * (p.tp / 100.0));                   // TRMWavetable.m:71-75
     c.tableDiv2 = (int32_t)rint(512 * ((p.tp + p.tnMax) / 100.0));
     c.invDiv1 = c.tableDiv1 > 0 ? (float)(1.0 / c.tableDiv1) : 0.0f;

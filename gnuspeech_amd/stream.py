@@ -8,12 +8,22 @@ import numpy as np
 from ._capi import check, lib
 
 
+MODES = {"framework": 0, "tract": 1}      # TRM_STREAM_MODE_* (include/trm_c_api.h)
+
+
 class TRMStream:
-    def __init__(self, inputParameters, nvoices=1, device=-1):
+    def __init__(self, inputParameters, nvoices=1, device=-1, mode="framework"):
         self._h = C.c_void_p()
         self.nvoices = int(nvoices)
         self.inputParameters = inputParameters
         check(lib().trm_stream_create(C.byref(inputParameters.c), device, self.nvoices, C.byref(self._h)))
+        if mode != "framework":
+            self.set_mode(mode)
+
+    def set_mode(self, mode):
+        """"framework": Frameworks/Tube's loop (interpolated control periods); "tract": Applications/TRAcT/tube.c's own
+        (every frame one control period of held parameters, x10 frication taps, x100 output; tube.c:1096-1190, 1371)."""
+        check(lib().trm_stream_set_mode(self._h, MODES[mode]))
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -311,6 +311,19 @@ int  trm_batch_generate_frames_host(trm_batch *batch, const uint32_t *event_time
 typedef struct trm_stream trm_stream;
 int  trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out);
 void trm_stream_destroy(trm_stream *stream);
+/* Whose sample loop the stream follows.  Applications/TRAcT/tube.c's real-time loop (tube.c:1096-1190) is the ancestor of
+ * Frameworks/Tube's and differs from it in three documented ways; TRM_STREAM_MODE_TRACT reproduces them so that
+ * shim/tract_tube.c sounds like tube.c:
+ *   - no control-rate interpolation: tube.c converts `current.*` every sample (tube.c:1121-1136), a slider write takes effect at
+ *     once.  Here EVERY pushed frame (the first one too) is one control period of HELD parameters: a change steps at
+ *     the push boundary (TRM_STREAM_MODE_FRAMEWORK: the first frame is the starting point and every later frame one period
+ *     interpolated from the frame before it, TRMTubeModel.m:611-688);
+ *   - the frication taps carry ten times the amplitude (tube.c:1371 vs TRMTubeModel.m:750);
+ *   - the output is 100 times louder (tube.c:1177; applied to the converter's output here, before it there: linear).
+ * Only between utterances (before the first push or after trm_stream_finish); TRM_EINVAL otherwise. */
+enum { TRM_STREAM_MODE_FRAMEWORK = 0, TRM_STREAM_MODE_TRACT = 1 };
+int  trm_stream_set_mode(trm_stream *stream, int mode);
+int  trm_stream_mode(const trm_stream *stream);
 /* Exact number of samples per voice the next push of `nframes` frames (resp. the finish call) returns. */
 size_t trm_stream_samples_for_push(const trm_stream *stream, size_t nframes);
 size_t trm_stream_samples_for_finish(const trm_stream *stream);

@@ -459,9 +459,10 @@ static void tube_coefficients(tube_t *t)
 }
 
 /* -setFricationTaps (:748-773) */
-static void frication_taps(tube_t *t)
+static void frication_taps(tube_t *t, int tract)
 {
     double amp = trm_oracle_amplitude(t->current[F_FRICVOL]);
+    if (tract) amp = 10 * amp;                      /* Applications/TRAcT/tube.c:1371 "Volume x 10 to be audible" */
     int32_t ip = (int32_t)t->current[F_FRICPOS];
     double complement = t->current[F_FRICPOS] - (double)ip;
     double remainder = 1.0 - complement;
@@ -605,8 +606,13 @@ static void tube_push(tube_t *t, double v)
     t->tube[t->ntube++] = v;
 }
 
-int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_t nframes,
-                          int keep_tube_samples, trm_oracle_result *out)
+/* tract != 0: the sample loop of Applications/TRAcT/tube.c (its synthesize() thread, tube.c:1096-1190) instead of
+ * Frameworks/Tube's: frame f is the parameter set `current` holds during control period f -- no interpolation
+ * (tube.c:1121-1136 converts current.* every sample) --, ten times the frication amplitude (tube.c:1371), the tube-rate
+ * sample times 100 before the converter (tube.c:1177).  Pinned against the reference binary run in that order
+ * (oracle/ref_driver.c `tract`, tests/golden/tract_mode_*.npz). */
+static int synthesize_impl(const trm_input_params *p, const double *frames, size_t nframes,
+                           int keep_tube_samples, trm_oracle_result *out, int tract)
 {
     if (!p || !out || (nframes && !frames)) return TRM_EINVAL;
     memset(out, 0, sizeof *out);
@@ -618,13 +624,13 @@ int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_
 
     if (nframes > 0) {                                                          /* TRMTubeModel.m:274-277 */
         for (size_t f = 1; f < nframes; f++) {                                  /* :282-357 */
-            set_control_rate(t, frames + 16 * f, frames + 16 * (f - 1));
+            set_control_rate(t, frames + 16 * f, frames + 16 * (tract ? f : f - 1));
             for (int32_t j = 0; j < t->controlPeriod; j++) {
                 double f0 = trm_oracle_frequency(t->current[F_PITCH]);          /* :294-296 */
                 double ax = trm_oracle_amplitude(t->current[F_GLOTVOL]);
                 double ah1 = trm_oracle_amplitude(t->current[F_ASPVOL]);
                 tube_coefficients(t);                                           /* :298 */
-                frication_taps(t);                                              /* :299 */
+                frication_taps(t, tract);                                       /* :299 */
                 {                                                               /* :300, TRMFilters.m:9-17 */
                     double tanv = tan((M_PI * t->current[F_FRICBW]) / t->sampleRate);
                     double cosv = cos((2.0 * M_PI * t->current[F_FRICCF]) / t->sampleRate);
@@ -662,6 +668,7 @@ int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_
                     t->throatY = y;
                     signal += y * t->throatGain;
                 }
+                if (tract) signal = signal * 100;                               /* tube.c:1177 */
                 tube_push(t, signal);
                 data_fill(t, signal);                                           /* :346 */
                 for (int i = 0; i < 16; i++) t->current[i] += t->delta[i];      /* :351, :676-688 */
@@ -679,6 +686,18 @@ int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_
     free(t);
     if (rc) trm_oracle_result_free(out);
     return rc;
+}
+
+int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_t nframes,
+                          int keep_tube_samples, trm_oracle_result *out)
+{
+    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 0);
+}
+
+int trm_oracle_synthesize_tract(const trm_input_params *p, const double *frames, size_t nframes,
+                                int keep_tube_samples, trm_oracle_result *out)
+{
+    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 1);
 }
 
 /* bench.py's cpu_baseline leg: `count` voices of `nframes` frames each (frames = [voices][nframes][16] doubles),

@@ -36,6 +36,11 @@ typedef struct trm_oracle_result {
  * frames = nframes x 16 doubles in file column order.  Returns a TRM_* code. */
 int  trm_oracle_synthesize(const trm_input_params *params, const double *frames, size_t nframes,
                            int keep_tube_samples, trm_oracle_result *out);
+/* The same in the loop order of Applications/TRAcT/tube.c (tube.c:1096-1190): frame f (f >= 1) is HELD for control period f,
+ * frication taps x10 (tube.c:1371), tube-rate sample x100 before the converter (tube.c:1177).  Frame 0 is ignored, as
+ * oracle/ref_driver.c `tract` ignores it. */
+int  trm_oracle_synthesize_tract(const trm_input_params *params, const double *frames, size_t nframes,
+                                 int keep_tube_samples, trm_oracle_result *out);
 void trm_oracle_result_free(trm_oracle_result *r);
 /* `count` voices in a row on the calling thread (bench.py's cpu_baseline: one call per thread, no Python in the loop) */
 int  trm_oracle_run_voices(const trm_input_params *params, const double *frames, size_t nframes, size_t nvoices,

@@ -9,14 +9,16 @@
  *   initializeSynthesizer() (tube.c:580-680)            (re)creates the stream from the utterance-rate globals and
  *                                                       starts the synthesis thread once
  *   synthesize() thread (tube.c:1096-1190): one tube    synthesis thread: one control period per trm_stream_push of
- *   sample per iteration from `current`, no             the current parameter set (the GPU interpolates from the set
- *   interpolation, dataFill -> dataEmpty -> circBuff2   pushed before, TRMTubeModel.m:611-688: parameter changes glide
- *                                                       over one control period instead of stepping), PCM -> circBuff2
+ *   sample per iteration from `current`, no             the current parameter set, in TRM_STREAM_MODE_TRACT: the set is
+ *   interpolation, x10 frication taps (:1371), x100     HELD for the period (a slider write steps at the next push, not
+ *   (:1177), dataFill -> dataEmpty -> circBuff2         glides), frication taps x10, output x100; PCM -> circBuff2
  *   getCircBuff2() (tube.c:3197-3230), circBuff2Count   the same blocking pop and counter (Controller.m:88-91)
  *
- * Known differences from tube.c, all documented divergences of TRAcT from Frameworks/Tube: the x100 gain
- * before the converter (tube.c:1180) is applied here after it (the converter is linear); the x10 frication-tap gain
- * is not reproduced; the converter output is the library's fp32.
+ * What remains different from tube.c: a slider write takes effect at the next control-period boundary (tube.c: at the
+ * next sample; the boundary is <= 10 ms away at TRAcT's control rate of 100 Hz); the x100 gain is applied to the
+ * converter's output (tube.c: to its input; the converter is linear); the converter output is the library's fp32.
+ * tests/test_tract_shim.py plays Controller.m's part and checks what comes out of circBuff2 against the REFERENCE's
+ * tube.c run in its own loop order (tests/golden/tract_mode_*.npz) over whole utterances, slider moves included.
  */
 #include <math.h>
 #include <pthread.h>
@@ -165,7 +167,7 @@ static void *synthesize(void *unused)          /* tube.c:1096-1190 */
         int rc = trm_stream_push(stream, f, 1, out, cap ? cap : 1, &got, NULL);
         pthread_mutex_unlock(&streamMutex);
         if (rc) { fprintf(stderr, "tract_tube: %s\n", trm_last_error()); break; }
-        for (uint32_t i = 0; i < got; i++) put_sample(out[i] * 100.0f);        /* tube.c:1180 */
+        for (uint32_t i = 0; i < got; i++) put_sample(out[i]);                 /* (x100, tube.c:1177: done by the mode) */
     }
     free(out);
     return NULL;
@@ -199,10 +201,12 @@ int initializeSynthesizer(void)                 /* tube.c:580-680 */
     pthread_mutex_lock(&streamMutex);
     trm_stream *ns = NULL;
     int rc = trm_stream_create(&p, -1, 1, &ns);
+    if (rc == 0) rc = trm_stream_set_mode(ns, TRM_STREAM_MODE_TRACT);          /* tube.c's own loop order */
     if (rc == 0) {
         if (stream) trm_stream_destroy(stream);
         stream = ns;
-    }
+    } else if (ns)
+        trm_stream_destroy(ns);
     pthread_mutex_unlock(&streamMutex);
     if (rc) { fprintf(stderr, "tract_tube: %s\n", trm_last_error()); return -1; }
     if (threadFlag == 0) {                      /* tube.c:660-670 */

@@ -14,13 +14,16 @@
 
 using namespace trm;
 
-extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frames, size_t nframes,
-                                   float *out, size_t cap, uint32_t *nout, float *maxv, float *tube)
+// tract: the loop order of Applications/TRAcT/tube.c as the streaming kernel runs it in TRM_STREAM_MODE_TRACT (frame f held
+// for control period f, frication amplitude x10 in the coefficient stage, x100 on the converter's output)
+static int emul_synthesize(const trm_input_params *p, const float *frames, size_t nframes,
+                           float *out, size_t cap, uint32_t *nout, float *maxv, float *tube, bool tract)
 {
     Const C;
     trm_derived d;
     int rc = build_const(*p, C, d);
     if (rc) return rc;
+    if (tract) C.fricGain = 10.0f;
     if (!C.upsample) return TRM_ERANGE;
     static std::vector<float> rows, sine;
     if (rows.empty()) { build_src_rows(rows); build_sine_table(sine); }
@@ -45,11 +48,11 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
     std::vector<float> sig(25 + ntube + 2 * C.padSize, 0.0f);
     size_t n = 0;
     for (size_t f = 1; f < nframes; f++) {
-        excite_track_setup(ET, C, frames + 16 * (f - 1), frames + 16 * f);
-        coef_track_setup(CT, C, frames + 16 * (f - 1), frames + 16 * f);
+        excite_track_setup(ET, C, frames + 16 * (tract ? f : f - 1), frames + 16 * f);
+        coef_track_setup(CT, C, frames + 16 * (tract ? f : f - 1), frames + 16 * f);
         for (int j = 0; j < C.controlPeriod; j++) {
             Excitation E = excite_sample(ES, ET, C, C.fir, j, lp[n], sineLookup);
-            Coefs K = coef_sample(CT, C, j);
+            Coefs K = tract ? coef_sample<true>(CT, C, j) : coef_sample(CT, C, j);
             float s = tube_sample(TS, C, E, K);
             if (tube) tube[n] = s;
             sig[25 + n] = s;
@@ -62,6 +65,7 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
         uint32_t ph = src_phase((uint32_t)k, C.timeRegisterIncrement);
         uint32_t e = src_position((uint32_t)k, C.timeRegisterIncrement);
         float y = src_dot(&sig[e], &rows[(size_t)ph * kSrcRowC]);
+        if (tract) y *= 100.0f;
         if (k < cap) out[k] = y;
         float a = fabsf(y);
         if (a > mx) mx = a;
@@ -69,6 +73,18 @@ extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frame
     *nout = (uint32_t)total;
     *maxv = mx;
     return TRM_OK;
+}
+
+extern "C" int trm_emul_synthesize(const trm_input_params *p, const float *frames, size_t nframes,
+                                   float *out, size_t cap, uint32_t *nout, float *maxv, float *tube)
+{
+    return emul_synthesize(p, frames, nframes, out, cap, nout, maxv, tube, false);
+}
+
+extern "C" int trm_emul_synthesize_tract(const trm_input_params *p, const float *frames, size_t nframes,
+                                         float *out, size_t cap, uint32_t *nout, float *maxv, float *tube)
+{
+    return emul_synthesize(p, frames, nframes, out, cap, nout, maxv, tube, true);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -155,7 +155,24 @@ def tract_mode_cases():
     held for 68 control periods (29 988 outputs), then one radius stepped to (float)0.4 and held for 68 more."""
     fr = static_frames(TRACT_SHIM_FRAME, 138)
     fr[TRACT_STEP_FRAME:, 7 + 6] = float(np.float32(0.4))
-    return {"tract_mode_ee_step": (tract_shim_params(), fr)}
+    out = {"tract_mode_ee_step": (tract_shim_params(), fr)}
+    # a held fricative posture: frication at a fractional position (two taps), aspiration, a narrow constriction --
+    # the inputs on which tube.c's x10 frication taps (tube.c:1371) show
+    out["tract_mode_fricative"] = (tract_shim_params(), static_frames(np.float32(TRACT_FRIC_FRAME).astype(np.float64), 70))   # (fp32-exact: what the stream receives)
+    # sliders moving while it plays: the vowel, then (period TRACT_FRIC_ON) a constriction + frication + aspiration,
+    # then (period TRACT_FRIC_MOVE) the frication position / centre frequency / volume move: every change STEPS
+    fr = static_frames(TRACT_SHIM_FRAME, 138)
+    fr[TRACT_FRIC_ON:, [2, 3, 4, 5, 6]] = np.float32([12.0, 42.5, 5.3, 3500.0, 1800.0]).astype(np.float64)
+    fr[TRACT_FRIC_ON:, 7 + 5] = float(np.float32(0.2))
+    fr[TRACT_FRIC_MOVE:, [3, 4, 5]] = np.float32([55.0, 6.75, 2500.0]).astype(np.float64)
+    fr[TRACT_FRIC_MOVE:, 1] = 48.0
+    out["tract_mode_fric_step"] = (tract_shim_params(), fr)
+    return out
+
+
+# pitch, glotVol, aspVol, fricVol, fricPos, fricCF, fricBW, r1..r8, velum
+TRACT_FRIC_FRAME = [-2.0, 54.0, 20.0, 45.0, 5.4, 4500.0, 2000.0, 0.8, 1.2, 1.5, 1.7, 1.4, 0.25, 0.9, 1.2, 0.0]
+TRACT_FRIC_ON, TRACT_FRIC_MOVE = 40, 85
 
 
 # ---------------------------------------------------------------- what a randomized parity run may NOT be asked to match

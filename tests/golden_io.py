@@ -10,6 +10,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE_NAMES = ["tract_vowel_1s", "monet_vowel_44k", "monet_vowel_22k", "gnuspeech_input_22k",
               "gnuspeech_window_44k", "sine_nomod", "frication_sweep", "short_tube_downsample",
               "female_15cm_stereo"]
+# the reference's tube.c stepped in TRAcT's OWN loop order (oracle/ref_driver.c `tract`)
+TRACT_CASE_NAMES = ["tract_mode_ee_step", "tract_mode_fricative", "tract_mode_fric_step"]
 
 
 def load(name):

@@ -78,6 +78,8 @@ def lib():
         L.trm_oracle_synthesize.argtypes = [C.POINTER(InputParams), C.POINTER(C.c_double), C.c_size_t,
                                             C.c_int, C.POINTER(_Result)]
         L.trm_oracle_synthesize.restype = C.c_int
+        L.trm_oracle_synthesize_tract.argtypes = L.trm_oracle_synthesize.argtypes
+        L.trm_oracle_synthesize_tract.restype = C.c_int
         L.trm_oracle_result_free.argtypes = [C.POINTER(_Result)]
         L.trm_oracle_run_voices.argtypes = [C.POINTER(InputParams), C.POINTER(C.c_double), C.c_size_t, C.c_size_t,
                                             C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
@@ -111,12 +113,14 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def synthesize(params, frames, keep_tube=False):
+def synthesize(params, frames, keep_tube=False, tract=False):
     """Run the oracle.  frames: [n,16] float64.  Returns dict(samples, numberSamples,
-    maximumSampleValue, tubeSamples, derived)."""
+    maximumSampleValue, tubeSamples, derived).  tract: in the loop order of Applications/TRAcT/tube.c (frame f >= 1 held
+    for control period f, x10 frication taps, x100 before the converter; oracle/trm_oracle.h)."""
     frames = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 16)
     res = _Result()
-    rc = lib().trm_oracle_synthesize(C.byref(params), _dptr(frames), frames.shape[0], int(keep_tube), C.byref(res))
+    fn = lib().trm_oracle_synthesize_tract if tract else lib().trm_oracle_synthesize
+    rc = fn(C.byref(params), _dptr(frames), frames.shape[0], int(keep_tube), C.byref(res))
     if rc != 0:
         raise RuntimeError("trm_oracle_synthesize rc=%d" % rc)
     n = res.numberSamples

@@ -158,14 +158,49 @@ def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
-def test_bench_traffic_file_is_stamped_with_the_kernel_sources():
-    """profiles/traffic_r02.json (what bench.py quotes roofline.traffic from) carries the hash of the kernel sources it was
-    measured on; bench.kernel_source_hash() is what bench.py compares it with (a stale file is refused, not quoted)."""
+def test_bench_traffic_file_is_stamped_with_the_kernel_sources(tmp_path, monkeypatch):
+    """profiles/traffic_r03.json (what bench.py quotes roofline.traffic / valu_issue from) is a LIST of PMC results keyed by
+    workload and kernel form, stamped as a whole with the hash of the kernel sources it was measured on: a stale file is
+    refused, an entry is quoted only for its own workload in its own kernel form."""
     import json, sys
     sys.path.insert(0, ROOT)
     import bench
     h = bench.kernel_source_hash()
     assert len(h) == 16 and int(h, 16) >= 0
-    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
-    assert set(("kernel_source_sha16", "workload", "traffic_bytes_per_launch", "SQ_INSTS_VALU", "issue_cycles_per_valu")) <= set(tj)
-    assert tj["workload"]["kernel_form"] in ("oct", "quad", "wide")
+    entry = {"workload": {"voices_per_gpu": 65536, "frames_per_voice": 251, "kind": "static", "kernel_form": "wide"},
+             "traffic_bytes_per_launch": 123, "SQ_INSTS_VALU": 1.0e9, "issue_cycles_per_valu": 3.0, "source": "x", "issue_cycles_source": "y"}
+    f = tmp_path / "traffic.json"
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+    assert bench.lookup_traffic(65536, 251, "static", "wide", 1e-3)[0] is None            # no file
+    f.write_text(json.dumps({"kernel_source_sha16": "0" * 16, "entries": [entry]}))
+    t, v, note = bench.lookup_traffic(65536, 251, "static", "wide", 1e-3)
+    assert t is None and v is None and "stale" in note
+    f.write_text(json.dumps({"kernel_source_sha16": h, "entries": [entry]}))
+    t, v, note = bench.lookup_traffic(65536, 251, "static", "wide", 1e-3)
+    assert t == 123 and abs(v["frac_of_issue_slots"] - 1.0e9 * 3.0 / (1e-3 * 2.4e9 * 1024)) < 1e-12
+    assert bench.lookup_traffic(65536, 251, "static", "oct", 1e-3)[0] is None             # another kernel form
+    assert bench.lookup_traffic(4096, 251, "static", "wide", 1e-3)[0] is None             # another batch
+    # the committed file, where there is one, has this shape
+    committed = os.path.join(ROOT, "profiles", "traffic_r03.json")
+    if os.path.exists(committed):
+        tj = json.load(open(committed))
+        assert set(("kernel_source_sha16", "entries")) <= set(tj) and len(tj["entries"]) >= 1
+        for e in tj["entries"]:
+            assert set(("workload", "traffic_bytes_per_launch", "SQ_INSTS_VALU", "issue_cycles_per_valu", "source")) <= set(e)
+            assert e["workload"]["kernel_form"] in ("oct", "quad", "wide")
+
+
+def test_bench_config_flag_names_the_per_gpu_workload():
+    """--config K = BASELINE.json configs[K] per GPU whatever --gpus says: `--gpus 1 --config 4` is exactly one GPU's shard of
+    configs[4], the run an N-rank line's `scaling_baseline` names (N = 1 and N > 1 ran different workloads
+    with no way to run the same one on one GPU)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resolve_workload(bench.parse_args([]), 1) == (1, 4096, "static")
+    assert bench.resolve_workload(bench.parse_args(["--gpus", "8"]), 8) == (4, 8192, "timevarying")
+    assert bench.resolve_workload(bench.parse_args(["--gpus", "1", "--config", "4"]), 1) == (4, 8192, "timevarying")
+    assert bench.resolve_workload(bench.parse_args(["--gpus", "2", "--config", "1"]), 2) == (1, 4096, "static")
+    assert bench.resolve_workload(bench.parse_args(["--config", "2"]), 1) == (2, 4096, "timevarying")
+    assert bench.resolve_workload(bench.parse_args(["--voices", "65536", "--kernel", "wide"]), 1) == (1, 65536, "static")
+    assert bench.parse_args([]).steps == 200          # half a second of GPU work: the driver's sampler sees the run

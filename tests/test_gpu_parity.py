@@ -350,13 +350,25 @@ def test_synthesizer_facade_and_writers(g, tmp_path):
         assert len(body) == len(ref) and np.max(np.abs(diff)) <= 8
 
 
-def test_cli_batch_directory_equals_single_file_mode(g, tmp_path):
-    """tools/softwaretrm.py --batch: every file of a directory in one launch per parameter set; each output file
+def cli_argv(tool):
+    """The two builds of the softwareTRM command line tool (Frameworks/Tube/main.m:12-67): "c" = tools/softwaretrm.c, plain C
+    over the C ABI, built next to the library by gnuspeech_amd/csrc/Makefile; "py" = tools/softwaretrm.py over ctypes."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if tool == "c":
+        exe = os.path.join(root, "gnuspeech_amd", "softwaretrm")
+        assert os.path.exists(exe), "gnuspeech_amd/softwaretrm missing: make -C gnuspeech_amd/csrc"
+        return [exe]
+    return [sys.executable, os.path.join(root, "tools", "softwaretrm.py")]
+
+
+@pytest.mark.parametrize("tool", ["c", "py"])
+def test_cli_batch_directory_equals_single_file_mode(g, tmp_path, tool):
+    """softwaretrm --batch: every file of a directory in one launch per parameter set; each output file
     is byte-identical to what the reference-shaped single-file mode (Frameworks/Tube/main.m:12-67) writes."""
     import os
     import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     indir, out_b, out_s = tmp_path / "in", tmp_path / "batch", tmp_path / "single"
     os.makedirs(indir)
     os.makedirs(out_s)
@@ -371,24 +383,68 @@ def test_cli_batch_directory_equals_single_file_mode(g, tmp_path):
         name = "utt%d.trm" % i
         dl.writeToFile(str(indir / name))
         names.append((name, ".wav" if fmt == 2 else ".au"))
-    tool = os.path.join(root, "tools", "softwaretrm.py")
-    r = subprocess.run([sys.executable, tool, "--batch", str(indir), str(out_b)], capture_output=True, text=True)
+    r = subprocess.run(cli_argv(tool) + ["--batch", str(indir), str(out_b)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "4 files in 2 launches" in r.stdout
     for name, ext in names:
         single = str(out_s / (name[:-4] + ext))
-        r = subprocess.run([sys.executable, tool, str(indir / name), single], capture_output=True, text=True)
+        r = subprocess.run(cli_argv(tool) + [str(indir / name), single], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert open(single, "rb").read() == open(str(out_b / (name[:-4] + ext)), "rb").read()
 
 
-def test_cli_verbose_prints_input_data_like_the_reference(g, tmp_path):
+@pytest.mark.parametrize("fmt,channels", [(0, 1), (1, 2), (2, 2), (2, 1)])
+def test_c_cli_writes_the_same_files_as_the_python_cli(g, tmp_path, fmt, channels):
+    """tools/softwaretrm.c (the first C caller of the trm_tube_* half of the ABI: trm_data_list_read_file -> trm_tube_create ->
+    trm_tube_synthesize -> trm_tube_save_output_to_file) against tools/softwaretrm.py: AU / AIFF / WAVE, mono and stereo,
+    byte for byte; and the int16 payload against the ORACLE's scaling of the oracle's samples (<= 1 LSB)."""
+    import subprocess
+    pd = cases.monet_default_params(22050.0)
+    pd.update(outputFileFormat=fmt, channels=channels, balance=0.3, volume=54.0)
+    rows = cases.load_gnuspeech_rows()[40:90]
+    dl = g.TRMDataList()
+    dl.inputParameters = g.TRMInputParameters.from_dict(pd)
+    dl.values = [g.TRMParameters(r) for r in rows]
+    inp = str(tmp_path / "a.trm")
+    dl.writeToFile(inp)
+    outs = {}
+    for tool in ("c", "py"):
+        out = str(tmp_path / ("out_" + tool))
+        r = subprocess.run(cli_argv(tool) + [inp, out], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == "", (r.stdout, r.stderr)        # silent without -v (main.m)
+        outs[tool] = open(out, "rb").read()
+    assert outs["c"] == outs["py"]
+    raw = outs["c"]
+    hdr = {0: 24, 1: 54, 2: 44}[fmt]
+    body = np.frombuffer(raw[hdr:], dtype="<i2" if fmt == 2 else ">i2").astype(np.int32)
+    back = g.TRMDataList.initWithContentsOfFile(inp)
+    op = O.InputParams.from_dict(pd)
+    o = O.synthesize(op, back.frame_array().astype(np.float64))
+    ref = O.scale_int16(op, o["samples"], o["maximumSampleValue"]).astype(np.int32)
+    assert body.size == ref.size
+    diff = ((body - ref + 32768) % 65536) - 32768            # (balance 0.3 x2 wraps the right channel like the reference's cast)
+    assert np.max(np.abs(diff)) <= 1
+
+
+def test_c_cli_usage_and_failures(g, tmp_path):
+    """Messages and exit codes of Frameworks/Tube/main.m:18-42."""
+    import subprocess
+    exe = cli_argv("c")[0]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 255 and r.stderr == "Usage:  %s [-v] inputFile outputFile\n" % exe
+    r = subprocess.run([exe, str(tmp_path / "missing.trm"), str(tmp_path / "x.au")], capture_output=True, text=True)
+    assert r.returncode == 255 and r.stderr.endswith("Aborting...\n")
+    bad = tmp_path / "bad.trm"
+    bad.write_text("0\n22050\n")                                 # truncated utterance-rate header (TRMDataList.m:53-214)
+    r = subprocess.run([exe, str(bad), str(tmp_path / "x.au")], capture_output=True, text=True)
+    assert r.returncode == 255 and r.stderr.endswith("Aborting...\n")
+
+
+@pytest.mark.parametrize("tool", ["c", "py"])
+def test_cli_verbose_prints_input_data_like_the_reference(g, tmp_path, tool):
     """softwareTRM -v (Frameworks/Tube/main.m:44-64): -printInputData's text (TRMDataList.m:251-330,
     TRMTubeModel.m:599-602) in the reference's formats, then the progress lines."""
-    import os
     import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pd = cases.monet_default_params(22050.0)
     pd.update(outputFileFormat=2, channels=2, balance=-0.25, volume=57.5)
     rows = cases.load_gnuspeech_rows()[30:33]
@@ -397,7 +453,7 @@ def test_cli_verbose_prints_input_data_like_the_reference(g, tmp_path):
     dl.values = [g.TRMParameters(r) for r in rows]
     inp, out = str(tmp_path / "a.trm"), str(tmp_path / "a.wav")
     dl.writeToFile(inp)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "softwaretrm.py"), "-v", inp, out], capture_output=True, text=True)
+    r = subprocess.run(cli_argv(tool) + ["-v", inp, out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     back = g.TRMDataList.initWithContentsOfFile(inp)           # (the file path doubles the last row, TRMDataList.m:239-241)
     p = back.inputParameters

@@ -31,6 +31,7 @@ def emul():
            C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     E.trm_emul_synthesize.argtypes = sig
     E.trm_emul_synthesize_quad.argtypes = sig
+    E.trm_emul_synthesize_tract.argtypes = sig
     E.trm_emul_quad_selfcheck.argtypes = [C.POINTER(O.InputParams), C.c_int, C.c_uint]
     E.trm_emul_oct_selfcheck.argtypes = [C.POINTER(O.InputParams), C.c_int, C.c_uint]
     return E
@@ -65,6 +66,23 @@ def test_both_formulations_against_oracle(emul, name):
         e = (out[:n.value].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
         assert float(np.sqrt(np.mean(e * e))) <= 1e-5
         assert abs(m.value - o["maximumSampleValue"]) / o["maximumSampleValue"] < 2e-4
+
+
+@pytest.mark.parametrize("name", golden_io.TRACT_CASE_NAMES)
+def test_tract_order_arithmetic_against_the_reference(emul, name):
+    """The device arithmetic in TRAcT's loop order (TRM_STREAM_MODE_TRACT: held parameters that step, x10 frication
+    amplitude, x100) on the host, against what the REFERENCE's tube.c produced in that order (tests/golden/tract_mode_*):
+    the whole utterance, stepped periods and fricative stretches included, at the one tolerance."""
+    g = golden_io.load(name)
+    p, fr = g["params"], np.ascontiguousarray(g["frames"], dtype=np.float32)
+    cap = len(fr) * 700 + 2000
+    out = np.zeros(cap, dtype=np.float32)
+    n, m = C.c_uint32(), C.c_float()
+    assert emul.trm_emul_synthesize_tract(C.byref(p), fr.ctypes.data_as(C.POINTER(C.c_float)), len(fr),
+                                          out.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n), C.byref(m), None) == 0
+    assert n.value == g["numberSamples"]
+    e = (out[:n.value].astype(np.float64) - g["samples_f32"].astype(np.float64)) / g["maximumSampleValue"]
+    assert float(np.sqrt(np.mean(e * e))) <= 1e-5
 
 
 def test_product_fir_table_equals_reference_taps(emul):

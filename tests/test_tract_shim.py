@@ -1,29 +1,35 @@
-"""shim/tract_tube.c: TRAcT's tube.h interface over a one-voice stream.  The C shim is compiled with
-gcc, driven like Controller.m drives tube.c (initializeSynthesizer, getCircBuff2, parameter writes through the getter
-pointers), and what comes out of its circular buffer is compared with the same held parameters pushed through the
-Python TRMStream mirror (bit for bit, x100 as tube.c:1180 scales)."""
+"""shim/tract_tube.c: TRAcT's tube.h interface over a one-voice stream in TRM_STREAM_MODE_TRACT.  The C
+shim is compiled with gcc and driven like Controller.m drives tube.c (initializeSynthesizer, getCircBuff2, parameter
+writes through the getter pointers); what comes out of its circular buffer is compared with the REFERENCE's tube.c run
+in its own loop order (tests/golden/tract_mode_*.npz, oracle/ref_driver.c `tract`) over the WHOLE utterance -- slider
+moves, fricative stretches, x10 frication taps, x100 gain included -- at the one tolerance, 1e-5."""
 import os
 import subprocess
 
 import numpy as np
 import pytest
 
+import cases
+import golden_io
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RING = 8192                # shim/tract_tube.c CIRC_BUFF2_SIZE == tube.c's
 
 
-def build_driver(tmp_path):
-    exe = str(tmp_path / "tract_shim_driver")
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("shim") / "tract_shim_driver")
     subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tests", "tract_shim_driver.c"),
                            os.path.join(ROOT, "shim", "tract_tube.c"), "-L" + os.path.join(ROOT, "gnuspeech_amd"),
                            "-l:libtrm_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "gnuspeech_amd"), "-lpthread", "-lm"])
     return exe
 
 
-def run_driver(exe, tmp_path, n1, n2, *mode):
+def run_driver(exe, tmp_path, total, *events):
     out = str(tmp_path / "heard.f32")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    r = subprocess.run([exe, out, str(n1), str(n2)] + list(mode), capture_output=True, text=True, env=env, timeout=120)
+    r = subprocess.run([exe, out, str(total)] + list(events), capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stderr
     return np.fromfile(out, dtype=np.float32), r
 
@@ -33,55 +39,72 @@ def nrms(x, ref, mx):
     return float(np.sqrt(np.mean(e * e)))
 
 
-def test_tract_shim_against_the_reference_in_tract_order(tmp_path):
-    """What the C shim plays, against tests/golden/tract_mode_ee_step: the REFERENCE's tube.c stepped in TRAcT's own loop
-    order (tube.c:1096-1190, oracle/ref_driver.c `tract`: x100 before the converter, parameters held per control period
-    and STEPPED when a slider moves).  Same bar as everywhere: normalised RMS <= 1e-5 -- on the held posture before the
-    slider moves and on the new steady state after it.  In between the two differ BY DESIGN and the test pins that too:
-    the shim glides to the new radius over one control period (Frameworks/Tube's interpolation, TRMTubeModel.m:611-688),
-    tube.c steps; and its x10 frication taps (tube.c:1371) are not reproduced (frication volume is 0 here)."""
-    import golden_io
-    gold = golden_io.load("tract_mode_ee_step")
-    want = gold["samples_f32"].astype(np.float64)
-    mx = gold["maximumSampleValue"]
-    n1, n2 = 30000, 30000
-    heard, _ = run_driver(build_driver(tmp_path), tmp_path, n1, n2, "radius")
-    assert heard.size == n1 + n2 and np.all(np.isfinite(heard))
-    # the golden's radius steps at control period 68 = output 29 988; the shim's thread runs up to its 8192-sample
-    # buffer ahead of what has been heard, so its change lands between outputs 30 000 and ~38 700
-    assert nrms(heard[:29000], want[:29000], mx) <= 1e-5
-    assert nrms(heard[n1 + 20000:n1 + n2], want[n1 + 20000:n1 + n2], mx) <= 1e-5      # new steady state, index for index
-    assert nrms(heard[n1:n1 + 10000], want[n1:n1 + 10000], mx) > 1e-3                    # the glide / the other change time
+def outputs_after(periods, gold):
+    """Converter outputs the stream has returned after `periods` control periods (trm_stream_samples_for_push's sum)."""
+    cp, inc = int(gold["derived"][0]), int(gold["derived"][4])
+    n = periods * cp
+    return 0 if n == 0 else ((n << 16) - 1) // inc + 1
 
 
-def test_tract_shim_plays_held_parameters(tmp_path):
+def move_at(period, gold, **values):
+    """The driver event that makes `values` the parameters of control period `period` (0-based) and later: written while
+    the synthesis thread is blocked in the middle of period - 1, RING samples ahead of what has been heard."""
+    mid = (outputs_after(period - 1, gold) + outputs_after(period, gold)) // 2
+    assert mid - RING > 0
+    return "%d:%s" % (mid - RING, ",".join("%s=%r" % (k, float(v)) for k, v in values.items()))
+
+
+FRAME_NAMES = ["glotPitch", "glotVol", "aspVol", "fricVol", "fricPos", "fricCF", "fricBW"] + ["r%d" % i for i in range(8)] + ["velum"]
+
+
+def events_from_frames(gold):
+    """Slider moves that turn the shim's start-up posture into the golden's frame sequence: frame f is what control
+    period f - 1 runs on (oracle/ref_driver.c `tract`)."""
+    fr = gold["frames"]
+    ev = []
+    start = np.float32(cases.TRACT_SHIM_FRAME).astype(np.float64)
+    if not np.array_equal(fr[1], start):
+        ev.append("-1:" + ",".join("%s=%r" % (FRAME_NAMES[i], float(fr[1][i])) for i in range(16) if fr[1][i] != start[i]))
+    for f in range(2, len(fr)):
+        ch = [i for i in range(16) if fr[f][i] != fr[f - 1][i]]
+        if ch:
+            ev.append(move_at(f - 1, gold, **{FRAME_NAMES[i]: fr[f][i] for i in ch}))
+    return ev
+
+
+@pytest.mark.parametrize("name", golden_io.TRACT_CASE_NAMES)
+def test_tract_shim_against_the_reference_in_tract_order(driver, tmp_path, name):
+    gold = golden_io.load(name)
+    assert gold["params_dict"] == cases.tract_shim_params()            # the shim's utterance-rate globals
+    want, mx = gold["samples_f32"].astype(np.float64), gold["maximumSampleValue"]
+    # everything the golden holds before its converter's flush (the shim never ends its utterance)
+    total = outputs_after(len(gold["frames"]) - 1, gold) - 64
+    ev = events_from_frames(gold)
+    assert len(ev) == {"tract_mode_ee_step": 1, "tract_mode_fricative": 1, "tract_mode_fric_step": 2}[name]
+    heard, r = run_driver(driver, tmp_path, total, *ev)
+    assert heard.size == total and np.all(np.isfinite(heard))
+    assert "controlPeriod %d" % int(gold["derived"][0]) in r.stdout
+    e = nrms(heard, want[:total], mx)
+    assert e <= 1e-5, "%s: normalised RMS %.3e over the whole utterance" % (name, e)
+    # and no stretch of it hides behind the average: every control period on its own (the stepped ones included)
+    per = int(round(44100.0 / 100.0))
+    worst = max(nrms(heard[i:i + per], want[i:i + per], mx) for i in range(0, total - per, per))
+    assert worst <= 1e-5, "%s: worst control period %.3e" % (name, worst)
+
+
+def test_tract_shim_equals_the_python_stream(driver, tmp_path):
+    """The C shim and gnuspeech_amd.TRMStream(mode="tract") are the same calls: bit for bit."""
     import gnuspeech_amd as g
-    n1, n2 = 30000, 30000
-    heard, r = run_driver(build_driver(tmp_path), tmp_path, n1, n2)
-    assert heard.size == n1 + n2 and np.all(np.isfinite(heard))
-    # the same held "ee" posture through the Python mirror of the stream API
-    # the shim's utterance-rate globals (shim/tract_tube.c, from Applications/TRAcT/tube.c:326-352)
-    pd = dict(outputFileFormat=1, outputRate=44100.0, controlRate=100.0, volume=60.0, channels=2, balance=0.0, waveform=0,
-              tp=35.0, tnMin=16.0, tnMax=40.0, breathiness=2.5, length=17.0, temperature=32.0, lossFactor=0.8, apScale=2.5,
-              mouthCoef=4000.0, noseCoef=4000.0, noseRadius=[1.35, 1.35, 1.7, 1.7, 1.3, 0.9], throatCutoff=1500.0,
-              throatVol=6.0, usesModulation=1, mixOffset=48.0)
-    frame = np.array([-0.0, 60, 0, 0, 8, 5000, 250, 0.8, 1.67, 1.905, 1.985, 0.81, 0.495, 0.73, 1.485, 0], dtype=np.float32)
-    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=1)
-    parts, total = [], 0
-    while total < n1:
-        o, _ = s.push(frame[None, None, :])
+    gold = golden_io.load("tract_mode_fric_step")
+    total = 40000
+    heard, _ = run_driver(driver, tmp_path, total, *events_from_frames(gold))
+    s = g.TRMStream(g.TRMInputParameters.from_dict(cases.tract_shim_params()), nvoices=1, mode="tract")
+    fr = gold["frames"].astype(np.float32)
+    parts, n = [], 0
+    for f in range(1, len(fr)):
+        o, _ = s.push(fr[f:f + 1])
         parts.append(o[0])
-        total += o.shape[1]
-    want = np.concatenate(parts)[:n1] * np.float32(100.0)
-    assert "controlPeriod %d" % s_derived_cp(g, pd) in r.stdout
-    assert np.array_equal(heard[:n1], want)
-    # after the parameter change the voice is still sounding, at another pitch: the spectrum moved
-    a, b = heard[n1 - 16384:n1], heard[-16384:]
-    assert np.abs(b).max() > 0.01 * np.abs(a).max()
-    fa, fb = np.abs(np.fft.rfft(a * np.hanning(a.size))), np.abs(np.fft.rfft(b * np.hanning(b.size)))
-    assert abs(int(np.argmax(fa[5:2000])) - int(np.argmax(fb[5:2000]))) > 3
-
-
-def s_derived_cp(g, pd):
-    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
-    return b.derived["controlPeriod"]
+        n += o.shape[1]
+        if n >= total:
+            break
+    assert np.array_equal(heard, np.concatenate(parts)[:total])
