@@ -120,8 +120,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         OscState S;
         ExciteTrack T;
         S.oscPos = 0.0;
-        float cur[4], prev[4];
-        if (nSteps > 0) load_frame(frames, 0, cur, 1);
+        // (both frames of a control period are fetched when it starts, once per ~80 samples: carrying the current frame
+        // to the next boundary in registers costs a register-to-register copy of it per STEP, the loop's phi nodes)
+        auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
         uint32_t j = CP, f = 0;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                     if (j == CP) {   // -setControlRateParameters:previous: (TRMTubeModel.m:289)
                         j = 0;
                         f++;
-                        for (int q = 0; q < 4; q++) prev[q] = cur[q];
-                        load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 1);
+                        float prev[4], cur[4];
+                        load_frame(frames, frame_at(f - 1), prev, 1);
+                        load_frame(frames, frame_at(f), cur, 1);
                         excite_track_setup(T, C, prev, cur);
                     }
                     OscOut O = osc_sample(S, T, C, (int)j, sine);
@@ -195,8 +197,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         // ------------------------------------------------------------ coef (this wave: samples of parity u), block i-1 at step i
         const int u = role - 2;
         CoefTrack T;
-        float cur[16], prev[16];
-        if (nSteps > 0) load_frame(frames, 0, cur, 4);
+        auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
         // position of this wave's next sample in its control period; the first sample starts period 1
         uint32_t j = CP + (uint32_t)u, f = 0;
         STAMP_DECL
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                 if (j >= CP) {      // the host guarantees CP >= 2*kTB: at most one period boundary per step
                     j -= CP;
                     f++;
-                    for (int q = 0; q < 16; q++) prev[q] = cur[q];
-                    load_frame(frames, f < nfr ? f : (nfr > 0 ? nfr - 1 : 0), cur, 4);
+                    float prev[16], cur[16];       // (fetched per period, not carried: see the oscillator wave)
+                    load_frame(frames, frame_at(f - 1), prev, 4);
+                    load_frame(frames, frame_at(f), cur, 4);
                     coef_track_setup(T, C, prev, cur);
                 }
                 Coefs K = coef_sample(T, C, (int)j);
@@ -236,6 +238,19 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         waves_reset(wA);
         waves_reset(wB);
         filters_reset(F);
+        // the step's constants as vector registers (tube_step): opaque moves, so that the compiler cannot go back to the
+        // kernel arguments' scalar registers.  (With the other round-3 changes 18.2 ms against 18.5 ms for the saturating
+        // batch, profiles/ab_r03.txt; on the round-2 kernel alone the same change measured 1 % slower.)
+        TubeConst TC;
+        float mA10v;
+        {
+            auto vcopy = [](float s) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s)); return r; };
+            TC.damping = vcopy(C.damping); TC.mCoeff = vcopy(C.mCoeff); TC.nCoeff = vcopy(C.nCoeff);
+            for (int i = 0; i < 4; i++) TC.nasalTd[i] = vcopy(C.nasalTd[i]);
+            TC.nasalK6a = vcopy(C.nasalK6a); TC.onePlusNK6 = vcopy(C.onePlusNK6);
+            TC.ta0 = vcopy(C.ta0); TC.tb1 = vcopy(C.tb1); TC.throatGain = vcopy(C.throatGain);
+            mA10v = vcopy(C.mA10);
+        }
         float *const ring = &sY[lane * kYStride];
         // down-sampling batches: tube-rate samples (and the zero flush) go to HBM for trm_downsample_kernel
         float *const tubeOut = A.tube_out ? A.tube_out + A.tube_offset[v] : nullptr;
@@ -249,14 +264,14 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             Coefs K;
             K.td[0] = k0.x; K.td[1] = k0.y; K.td[2] = k0.z; K.td[3] = k0.w;
             K.td[4] = k1.x; K.td[5] = k1.y; K.td[6] = k1.z; K.onePlusK8 = k1.w;
-            K.k8a = (K.onePlusK8 - 1.0f) * C.mA10;       // C8 a10 (C8 is near -1 when the mouth closes: no cancellation here)
+            K.k8a = (K.onePlusK8 - 1.0f) * mA10v;        // C8 a10 (C8 is near -1 when the mouth closes: no cancellation here)
             K.alphaU = k2.x; K.ntd1 = k2.y; K.bpBeta = k2.z; K.bpGamma = k2.w;
             K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);    // the three alphas sum to 2 (TRMTubeModel.m:733-736)
             K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;        // TRMFilters.m:16
             K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
             K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
             K.pad_ = 0.0f;
-            float y = tube_step(o, nw, F, C, E, K);
+            float y = tube_step(o, nw, F, TC, E, K);
             y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
             // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
             const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);

@@ -54,6 +54,18 @@ TRM_HD float fma_f(float a, float b, float c) { return __builtin_fmaf(a, b, c); 
 TRM_HD double exp2_d(double x) { return exp2(x); }
 TRM_HD double rint_d(double x) { return __builtin_rint(x); }
 TRM_HD float rint_f(float x) { return __builtin_rintf(x); }
+// a * b + c into a register of its OWN (v_fma_f32, three addresses), where the compiler would pick the two-address
+// v_fmac_f32 and accumulate in c's register: for a shift register held in VGPRs (the transposed FIR's partial sums) that
+// choice costs one v_mov per element and sample to move everything back at the loop's back edge
+TRM_HD float fma_new_f(float a, float b, float c)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// clamp to [0, 1]; NaN -> 0 (v_med3_f32 / the producing instruction's clamp modifier: a plain VGPR instruction where a
+// compare + select pair costs a shared SIMD twice as much, profiles/valu_ceiling_r02.txt)
+TRM_HD float sat_f(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 #else
 TRM_HD float rcp_f(float x) { return 1.0f / x; }
 TRM_HD float exp2_f(float x) { return exp2f(x); }
@@ -62,6 +74,8 @@ TRM_HD double fma_f(double a, double b, double c) { return fma(a, b, c); }   // 
 TRM_HD double exp2_d(double x) { return exp2(x); }
 TRM_HD double rint_d(double x) { return rint(x); }
 TRM_HD float rint_f(float x) { return rintf(x); }
+TRM_HD float sat_f(float x) { return x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f; }      // (NaN -> 0 like the device's)
+TRM_HD float fma_new_f(float a, float b, float c) { return fmaf(a, b, c); }
 #endif
 
 // sin / cos on [0, pi/4] (Taylor; truncation < 3e-8, below fp32 epsilon)
@@ -180,21 +194,29 @@ TRM_HD float sine_table(int i)
 // dB -> linear amplitude with the reference's clamps (TRMUtility.m:26-41), fp32.
 TRM_HD float amplitude_f(float db)
 {
-    float a = exp2_f((db - 60.0f) * 0.16609640474f);
-    a = db >= 60.0f ? 1.0f : a;
-    return db <= 0.0f ? 0.0f : a;
+    // the clamps as arithmetic: 2^x >= 1 exactly from db = 60 on, so "db >= 60 -> 1" is min(2^x, 1); "db <= 0 -> 0" is a
+    // factor that is 0 there and exactly 1 from db = 2^-100 on
+    const float a = sat_f(exp2_f((db - 60.0f) * 0.16609640474f));
+    return a * sat_f(db * 1.2676506e30f);
 }
 
 // One entry of the glottal pulse table as a pure function of the closure point
 // (TRMWavetable.m:79-96 rise/closed, :117-156 fall rewritten from the amplitude).
+// The three regions without a compare or a select: with x and xf clamped to [0, 1] the rise polynomial is exactly 1 from
+// the end of the rise on and the fall exactly 1 before its start, so the entry is their PRODUCT (one factor is always
+// exactly 1: the product is the other one, bit for bit); the closed phase is a factor that is exactly 1 below newDiv2
+// and 0 from there on (integers in floats).  fi = the entry's index as a float.
+TRM_HD float pulse_table_f(float fi, float fDiv1, float invDiv1, float fNewDiv2, float invFall)
+{
+    const float x = sat_f(fi * invDiv1);
+    const float rise = x * x * fma_f(-2.0f, x, 3.0f);
+    const float xf = sat_f((fi - fDiv1) * invFall);
+    const float fall = fma_f(-xf, xf, 1.0f);
+    return (rise * fall) * sat_f(fNewDiv2 - fi);
+}
 TRM_HD float pulse_table(int i, const Const &C, int newDiv2, float invFall)
 {
-    float x = (float)i * C.invDiv1;
-    float rise = x * x * fma_f(-2.0f, x, 3.0f);
-    float xf = (float)(i - C.tableDiv1) * invFall;
-    float fall = fma_f(-xf, xf, 1.0f);
-    float v = i < newDiv2 ? fall : 0.0f;
-    return i < C.tableDiv1 ? rise : v;
+    return pulse_table_f((float)i, (float)C.tableDiv1, C.invDiv1, (float)newDiv2, invFall);
 }
 
 // The excitation stage in two halves (they may run in different waves):
@@ -219,18 +241,19 @@ struct FirState {
 template <class SineLookup>
 TRM_HD void osc_read(const Const &C, double axd, double pos1, double pos2, SineLookup sineTab, float &wa, float &wb)
 {
-    int lo1 = (int)pos1, lo2 = (int)pos2;
+    int lo1 = (int)pos1, lo2 = (int)pos2;           // 0 .. 511: the position lies in (-1, 511] and the cast truncates (:183)
     float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
-    int up1 = lo1 + 1 > 511 ? lo1 + 1 - 512 : lo1 + 1;
-    int up2 = lo2 + 1 > 511 ? lo2 + 1 - 512 : lo2 + 1;
+    int up1 = (lo1 + 1) & (kTableLen - 1);          // mod0(lower + 1), :185
+    int up2 = (lo2 + 1) & (kTableLen - 1);
     float a0, a1, b0, b1;
     if (C.waveform == 0) {
         int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
         float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
-        a0 = pulse_table(lo1, C, newDiv2, invFall);
-        a1 = pulse_table(up1, C, newDiv2, invFall);
-        b0 = pulse_table(lo2, C, newDiv2, invFall);
-        b1 = pulse_table(up2, C, newDiv2, invFall);
+        const float fDiv1 = (float)C.tableDiv1, fNew = (float)newDiv2;
+        a0 = pulse_table_f((float)lo1, fDiv1, C.invDiv1, fNew, invFall);
+        a1 = pulse_table_f((float)up1, fDiv1, C.invDiv1, fNew, invFall);
+        b0 = pulse_table_f((float)lo2, fDiv1, C.invDiv1, fNew, invFall);
+        b1 = pulse_table_f((float)up2, fDiv1, C.invDiv1, fNew, invFall);
     } else {
         a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
     }
@@ -301,7 +324,8 @@ TRM_HD Excitation mix_sample(FirState &S, const Const &C, const float *fir, cons
     // (TRMFIRFilter.m:116-146); the partial sums shift for free through the FMA destination.
     auto c = [&](int i) { return fir[i < kFirUnique ? i : (kFirTaps - 1) - i]; };
     float pulse = fma_f(c(0), O.wb, fma_f(c(1), O.wa, S.fir[0]));
-    for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), O.wb, fma_f(c(2 * q + 3), O.wa, S.fir[q + 1]));
+    // (ascending q: element q's register is free when its new value is formed from element q + 1 -- no copies)
+    for (int q = 0; q < 23; q++) S.fir[q] = fma_f(c(2 * q + 2), O.wb, fma_new_f(c(2 * q + 3), O.wa, S.fir[q + 1]));
     S.fir[23] = c(48) * O.wb;
     return mix_tail(C, O.ax, O.ah1, pulse, lpNoise);
 }
@@ -480,7 +504,16 @@ TRM_HD void tube_reset(TubeState &S)
 
 // One sample: old waves `o` -> new waves `nw` (all new values from old values only, :778-853).
 // Returns the tube-rate output sample (what the reference hands to -dataFill:, :346).
-TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const Const &C, const Excitation &E, const Coefs &K)
+// CT: where the step's wave-uniform constants come from -- `Const` itself (kernel arguments: scalar registers) or a
+// TubeConst the caller filled with VECTOR-register copies (the one-voice-per-lane kernel: an instruction with a scalar
+// operand costs a shared SIMD 4.3 cycles instead of 2.4, profiles/valu_ceiling_r02.txt, and the damping factor alone
+// sits in half of the step's instructions).
+struct TubeConst {
+    float damping, mCoeff, nCoeff, nasalTd[4], nasalK6a, onePlusNK6, ta0, tb1, throatGain;
+};
+
+template <class CT>
+TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const CT &C, const Excitation &E, const Coefs &K)
 {
     // frication band-pass (TRMFilters.m:19-29), evaluated before the tract (:336-337)
     float fric = 2.0f * fma_f(K.bpAlpha, E.sig - L.bpX2, fma_f(K.bpGamma, L.bpY1, -(K.bpBeta * L.bpY2)));

@@ -47,6 +47,14 @@ enum { kXGin = 0, kXSig = 1, kXThr = 2, kXAlpha = 3 };
 // every lane of a group its own 16-byte bank slot 4 (p & 3) + (v & 3)  (the first layout, part rows of 8 + 2 records,
 // was 2-way conflicted there: SQ_LDS_BANK_CONFLICT 1.4e8 -> see profiles/)
 __host__ __device__ constexpr int oct_k_index(int p, int v) { return 16 * ((p >> 2) * 2 + (v >> 2)) + 4 * (p & 3) + (v & 3); }
+// Control frames, staged in LDS ahead of their use by LDS-DMA (the area wave, which has no other vector-memory traffic,
+// issues one 512-byte transfer per control period: 8 voices x 64 bytes) and read by the three waves that turn them into
+// tracks when a period starts.  Frame f lives in slot f % 8.  When the oscillator wave enters the period between frames
+// p and p+1, the stager retires the transfer of frame p+2 (sent for a whole period earlier: the wait is free) and sends
+// for frame p+3; frames p-1 .. p+1 are what the lagging waves may still be reading.  Carrying the prefetched frames in
+// REGISTERS instead (r01, r02) cost every coefficient wave 26 register-to-register copies per step -- the compiler's way
+// of keeping a conditionally rotated array across the loop's back edge -- a fifth of their instructions.
+constexpr int kFrameRing = 8;
 constexpr int kOKRow = 64 + 4;       // float4s per (buffer, sample): 64 records + 64 bytes, so that the writers' time slots
                                      // alternate between the two halves of the 32 write banks
 
@@ -62,8 +70,9 @@ struct OctLds {
     static constexpr size_t oInfo = oRows + sizeof(float) * kRowBufs * kCvtCols * kRowPitch;   // uint4 [kOV]
     static constexpr size_t oMx = oInfo + sizeof(uint4) * kOV;                            // float  [4 * kWave]
     static constexpr size_t oNoise = oMx + sizeof(float) * 4 * kWave;                     // float  [kNoiseRing]
-    static constexpr size_t oSync = oNoise + sizeof(float) * kNoiseRing;                  // uint32 [2]
-    static constexpr size_t kBytes = oSync + 16;
+    static constexpr size_t oSync = oNoise + sizeof(float) * kNoiseRing;                  // uint32 [2] (+ 8 bytes)
+    static constexpr size_t oFrames = oSync + 16;                                         // float4 [kFrameRing * kOV * 4]
+    static constexpr size_t kBytes = oFrames + sizeof(float4) * kFrameRing * kOV * 4;
     static_assert(oA % 16 == 0 && oX % 16 == 0 && oK % 16 == 0 && oY % 16 == 0 && oRows % 16 == 0 && oInfo % 16 == 0, "16-byte aligned pieces");
     static_assert(2 * kBytes <= 160 * 1024, "two workgroups per CU");
 };
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     float *const sMx = reinterpret_cast<float *>(sLds + L::oMx);
     float *const sNoise = reinterpret_cast<float *>(sLds + L::oNoise);
     uint32_t *const sRowSync = reinterpret_cast<uint32_t *>(sLds + L::oSync);   // [0] convert -> mix: first block whose staged rows are still needed; [1] mix -> convert: blocks staged
+    float4 *const sF = reinterpret_cast<float4 *>(sLds + L::oFrames);          // control frames [f % kFrameRing][voice][quarter]
 
     constexpr int kStampRoles = kORoles;
     (void)kStampRoles;
@@ -134,12 +144,31 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
     // the tube stage steps block i-4 at step i; the convert wave finishes what is queued after the last barrier
     const uint32_t nSteps = nTotal > 0 ? (nTotal + kOB - 1) / kOB + 5 : 0;
-    const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
-    auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
     // where sample `s` of block `blk` keeps this lane's voice's value of array `arr`
     auto x_at = [&](int arr, uint32_t blk, int s) -> float & { return sX[arr * kOXArray + ((blk % kXDepth) * kOB + s) * kOV + vq]; };
+
+    // this lane's voice's frame f (nominal index: past the voice's last frame the stager repeats it), quarter q
+    auto frame_q = [&](uint32_t f, int q) { return sF[((f % kFrameRing) * kOV + vq) * 4 + q]; };
+    auto frame_to = [&](uint32_t f, float *dst, int quads) {
+        for (int q = 0; q < quads; q++) {
+            const float4 x = frame_q(f, q);
+            dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w;
+        }
+    };
+    // the stager's lanes (area wave, lanes 0-31): lane -> (voice lane / 4, quarter lane % 4) of the workgroup's 8 frames
+    const float *stageSrc = nullptr;
+    uint32_t stageNfr = 0;
+    if (role == 2) {
+        const uint32_t sv = min(blockIdx.x * kOV + ((uint32_t)lane >> 2 & 7u), A.nvoices - 1);
+        stageNfr = min(A.nframes[sv], A.max_nframes);
+        stageSrc = A.frames + (stageNfr > 0 ? A.frame_offset[sv] * 16 : 0) + (lane & 3) * 4;
+    }
+    auto stage_frame = [&](uint32_t f) {
+        const uint32_t fi = stageNfr > 0 ? (f < stageNfr ? f : stageNfr - 1) : 0u;
+        if (lane < 32) dma16(stageSrc + (size_t)fi * 16, reinterpret_cast<float *>(&sF[(f % kFrameRing) * kOV * 4]));
+    };
 
     for (int i = threadIdx.x; i < kOV * kYStride; i += kThreads) sY[i] = 0.0f;
     for (int i = threadIdx.x; i < kOV * kOStride; i += kThreads) sO[i] = make_float2(0.0f, 0.0f);
@@ -152,6 +181,10 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         float4 *row = &sK[(i / kOV) * kOKRow];
         row[oct_k_index(6, i % kOV)] = make_float4(C.nasalTd[1], C.nasalTd[2], 0.0f, 0.0f);
         row[oct_k_index(7, i % kOV)] = make_float4(C.nasalTd[3], C.nasalK6a, 0.0f, C.onePlusNK6);
+    }
+    if (role == 2 && nSteps > 0) {
+        stage_frame(0); stage_frame(1); stage_frame(2); stage_frame(3);
+        dma_wait_all();
     }
     __syncthreads();
 
@@ -235,8 +268,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         // evaluated in one of a voice's four slots of the block and handed to the other three.
         OscSlotTrack T, Tn;
         double P = 0.0;                                 // oscillator position at the start of the step
-        float cur[4], nxt[4];                           // frames perN, perN + 1: the period after the one last set up runs between them
-        uint32_t perN = 1, bnd = CP;                    // bnd: first sample of that period
+        uint32_t perN = 1, bnd = CP;                    // the period after the one last set up runs between frames perN, perN + 1; bnd: its first sample
         uint32_t j = (uint32_t)slot;                    // position of this lane's sample in its control period
         auto setup_track = [&](OscSlotTrack &D, const float *fa, const float *fb, int jEntry) {
             double x[4], e[4];
@@ -249,11 +281,10 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
             osc_slot_from_exps<3>(D, C, fa, fb, jEntry, e);
         };
         if (nSteps > 0) {
-            float first[4];
-            load_frame(frames, frame_index(0), first, 1);
-            load_frame(frames, frame_index(1), cur, 1);
-            load_frame(frames, frame_index(2), nxt, 1);
-            setup_track(T, first, cur, (int)j);
+            float fa[4], fb[4];
+            frame_to(0, fa, 1);
+            frame_to(1, fb, 1);
+            setup_track(T, fa, fb, (int)j);
         }
         Tn = T;
         float2 *const ring = &sO[vq * kOStride];
@@ -271,10 +302,11 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
             if (step * kOB < nTotal) {
                 if (step * kOB + (kOB - 1) >= bnd) {        // (uniform) a lane enters the period that starts at sample bnd (:289)
                     const uint32_t ns = step * kOB + (uint32_t)slot;
-                    setup_track(Tn, cur, nxt, (int)(ns >= bnd ? ns - bnd : ns + kOB - bnd));
-                    for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+                    float fa[4], fb[4];
+                    frame_to(perN, fa, 1);
+                    frame_to(perN + 1, fb, 1);
+                    setup_track(Tn, fa, fb, (int)(ns >= bnd ? ns - bnd : ns + kOB - bnd));
                     perN++;
-                    load_frame(frames, frame_index(perN + 1), nxt, 1);     // (used one period from now)
                     bnd += CP;
                 }
                 if (j >= CP) {      // this lane's sample starts a control period
@@ -398,26 +430,34 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         ScanState Z;
         scans_reset(Z);
         CoefTrack T;
-        float cur[16], nxt[16];             // frames per + 1, per + 2 (the period's first frame lives on in T.base)
-        uint32_t per = 0, j = (uint32_t)slot;
+        uint32_t per = 0, j = (uint32_t)slot;      // the period between frames per and per + 1
         if (nSteps > 0) {
-            float first[16];
-            load_frame(frames, frame_index(0), first, 4);
-            load_frame(frames, frame_index(1), cur, 4);
-            load_frame(frames, frame_index(2), nxt, 4);
-            coef_track_setup(T, C, first, cur);
+            float fa[16], fb[16];
+            frame_to(0, fa, 4);
+            frame_to(1, fb, 4);
+            coef_track_setup(T, C, fa, fb);
         }
+        // the stager (area wave): in the step in which the oscillator wave enters the period between frames p and p + 1
+        // (it is two blocks ahead of this wave), the transfer of frame p + 2 is retired and frame p + 3 sent for
+        uint32_t stP = 1, stBnd = CP;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
+            if (area && step * kOB < nTotal && step * kOB + (kOB - 1) >= stBnd) {
+                dma_wait_all();
+                stage_frame(stP + 3);
+                stP++;
+                stBnd += CP;
+            }
             if (step >= 2 && (step - 2) * kOB < nTotal) {
                 const uint32_t blk = step - 2;
                 if (j >= CP) {
                     j -= CP;
                     per++;
-                    coef_track_setup(T, C, cur, nxt);
-                    for (int q = 0; q < 16; q++) cur[q] = nxt[q];
-                    load_frame(frames, frame_index(per + 2), nxt, 4);
+                    float fa[16], fb[16];
+                    frame_to(per, fa, 4);
+                    frame_to(per + 1, fb, 4);
+                    coef_track_setup(T, C, fa, fb);
                 }
                 Coefs K;
                 // [buf][slot][part p][voice]{k.x, k.y | in.x, in.y}: the area wave writes the k halves (and the mouth
@@ -448,6 +488,7 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
             STAMP_END
         }
         STAMP_STORE(role)
+        if (area) dma_wait_all();   // nothing may still be writing LDS when the wave ends
     } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
         // the only serial role: its instructions go first on the SIMD it shares with the other workgroup's waves

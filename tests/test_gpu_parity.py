@@ -4,6 +4,8 @@ Tolerance (BASELINE.json north_star): RMS error <= 1e-5 on output normalised by 
 maximumSampleValue; numberSamples must match exactly.  The HIP path computes the signal in fp32
 (fp64 only at the reference's discontinuities), so agreement is a tolerance, not bit-equality.
 """
+import re
+
 import numpy as np
 import pytest
 
@@ -411,17 +413,20 @@ def test_c_cli_writes_the_same_files_as_the_python_cli(g, tmp_path, fmt, channel
     for tool in ("c", "py"):
         out = str(tmp_path / ("out_" + tool))
         r = subprocess.run(cli_argv(tool) + [inp, out], capture_output=True, text=True)
-        assert r.returncode == 0 and r.stdout == "", (r.stdout, r.stderr)        # silent without -v (main.m)
-        outs[tool] = open(out, "rb").read()
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        outs[tool] = (open(out, "rb").read(), r.stdout)
     assert outs["c"] == outs["py"]
-    raw = outs["c"]
+    raw, said = outs["c"]
+    # without -v only what -saveOutputToFile: prints unconditionally (TRMTubeModel.m:372-376)
+    m = re.fullmatch(r"\nnumber of samples:\t(\d+)\nmaximum sample value:\t(\d+\.\d{4})\nscale:\t\t\t(\d+\.\d{4})\n", said)
+    assert m, repr(said)
     hdr = {0: 24, 1: 54, 2: 44}[fmt]
     body = np.frombuffer(raw[hdr:], dtype="<i2" if fmt == 2 else ">i2").astype(np.int32)
     back = g.TRMDataList.initWithContentsOfFile(inp)
     op = O.InputParams.from_dict(pd)
     o = O.synthesize(op, back.frame_array().astype(np.float64))
     ref = O.scale_int16(op, o["samples"], o["maximumSampleValue"]).astype(np.int32)
-    assert body.size == ref.size
+    assert body.size == ref.size and int(m.group(1)) * channels == ref.size
     diff = ((body - ref + 32768) % 65536) - 32768            # (balance 0.3 x2 wraps the right channel like the reference's cast)
     assert np.max(np.abs(diff)) <= 1
 

@@ -60,7 +60,7 @@ FRAME_NAMES = ["glotPitch", "glotVol", "aspVol", "fricVol", "fricPos", "fricCF",
 def events_from_frames(gold):
     """Slider moves that turn the shim's start-up posture into the golden's frame sequence: frame f is what control
     period f - 1 runs on (oracle/ref_driver.c `tract`)."""
-    fr = gold["frames"]
+    fr = gold["frames"].astype(np.float32).astype(np.float64)         # (the shim hands the library floats)
     ev = []
     start = np.float32(cases.TRACT_SHIM_FRAME).astype(np.float64)
     if not np.array_equal(fr[1], start):
