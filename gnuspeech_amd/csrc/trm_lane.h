@@ -96,6 +96,18 @@ TRM_HD float cos_q(float y)
     return fma_f(y2, p, 1.0f);
 }
 
+// sin on [0, pi/2] (Taylor to x^13; truncation < 7e-10)
+TRM_HD float sin_h(float y)
+{
+    float y2 = y * y;
+    float p = fma_f(y2, 1.6059044e-10f, -2.5052108e-8f);
+    p = fma_f(y2, p, 2.7557319e-6f);
+    p = fma_f(y2, p, -1.9841270e-4f);
+    p = fma_f(y2, p, 8.3333333e-3f);
+    p = fma_f(y2, p, -1.6666667e-1f);
+    return fma_f(y * y2, p, y);
+}
+
 // ---------------------------------------------------------------- wave-uniform constants
 // Derived once per batch on the host from trm_input_params (TRMTubeModel.m:196-241).
 struct Const {
@@ -427,25 +439,22 @@ TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j
         K.tap[i] = fmaxf(fma_f(-fricAmp, dist, fricAmp), 0.0f);
     }
 
-    // band-pass coefficients (TRMFilters.m:9-17): tan(pi*BW/SR), cos(2*pi*CF/SR)
+    // band-pass coefficients (TRMFilters.m:9-17): beta = (1 - t) / (2 (1 + t)), t = tan(pi BW / SR); gamma = (1/2 + beta)
+    // cos(2 pi CF / SR); alpha = (1/2 - beta) / 2.
     {
+        // (1 - tan x) / (1 + tan x) = tan(pi/4 - x): ONE tangent, and for every bandwidth the filter is stable at
+        // (0 <= BW <= SR/2) its argument lies in [-pi/4, pi/4], where the two polynomials hold -- no quadrant folding, no
+        // selects.  (Outside that range the reference's own output grows without bound: tests/cases.py bandpass_unstable.)
         float v = fricBW * C.invSampleRate;
         v = v - rint_f(v);                      // tan has period 1 in v
-        float a = fabsf(v);
-        bool hi = a > 0.25f;
-        float y = 3.14159265358979f * (hi ? 0.5f - a : a);
-        float s = sin_q(y), c = cos_q(y);
-        float num = hi ? c : s, den = hi ? s : c;     // tan = num/den
-        num = v < 0.0f ? -num : num;
-        K.bpBeta = (den - num) * rcp_f(2.0f * (den + num));   // (1-t)/(2(1+t))
+        const float y = 3.14159265358979f * (0.25f - v);
+        K.bpBeta = (0.5f * sin_q(y)) * rcp_f(cos_q(y));
+        // cos(2 pi u) = 1 - 2 sin^2(pi u), and with u reduced to [-1/2, 1/2] the sine's argument lies in [0, pi/2]: one
+        // odd polynomial (Taylor to x^13: truncation 7e-10), again without folding
         float u = fricCF * C.invSampleRate;
-        u = fabsf(u - rint_f(u));               // [0, .5]
-        bool neg = u > 0.25f;
-        u = neg ? 0.5f - u : u;                 // [0, .25]: angle in [0, pi/2]
-        bool swap = u > 0.125f;
-        float yy = 6.28318530717959f * (swap ? 0.25f - u : u);
-        float cv = swap ? sin_q(yy) : cos_q(yy);
-        cv = neg ? -cv : cv;
+        u = u - rint_f(u);
+        const float sh = sin_h(3.14159265358979f * fabsf(u));
+        const float cv = fma_f(-2.0f * sh, sh, 1.0f);
         K.bpGamma = (0.5f + K.bpBeta) * cv;
         K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;
     }

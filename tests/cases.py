@@ -178,12 +178,12 @@ TRACT_FRIC_ON, TRACT_FRIC_MOVE = 40, 85
 # ---------------------------------------------------------------- what a randomized parity run may NOT be asked to match
 def bandpass_unstable(frames, tube_rate):
     """The frication band-pass (TRMFilters.m:9-29) is y = 2 (alpha (x - x2) + gamma y1 - beta y2) with
-    2 beta = (1 - t) / (1 + t), t = tan(pi BW / SR): its poles leave the unit circle when t <= 0, i.e. from BW = SR / 2 on
+    2 beta = (1 - t) / (1 + t), t = tan(pi BW / SR): its poles leave the unit circle when t <= 0, i.e. from BW = SR / 2 on (and for BW < 0)
     (SR = the tube's sample rate).  A track that goes there makes the REFERENCE grow exponentially (outputs of 1e13 were
     seen): rounding differences are amplified without bound and no finite-precision path can match it.  Such a voice is
     outside the filter's domain and is reported as such, not compared."""
     fr = np.asarray(frames)
-    return bool(fr.size) and float(fr[:, 6].max()) >= 0.5 * float(tube_rate)
+    return bool(fr.size) and (float(fr[:, 6].max()) >= 0.5 * float(tube_rate) or float(fr[:, 6].min()) < 0.0)
 
 
 ABS_FLOOR = 1e-9     # absolute RMS below which a voice counts as matched whatever its own maximum is (a nearly silent
