@@ -479,6 +479,10 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // converter; tools/fuzz_parity.py at 96 kHz), so above 4 -- 96 kHz output from any adult tube, 64 kHz from 22 cm on --
     // the one-voice-per-lane form runs, whatever was asked for.
     if (which != TRM_KERNEL_WIDE && quad_ratio_too_high(b->c)) which = TRM_KERNEL_WIDE;
+    // ... and so it does for control periods below 24 tube samples (four lanes per voice; 16 with eight: control rates
+    // above ~0.8 / 1.2 kHz for an adult tube): those one-shot forms stage the control frames in LDS a period ahead, and a
+    // period must hold three (two) of their steps
+    if (which == TRM_KERNEL_QUAD && b->c.controlPeriod < 24) which = TRM_KERNEL_WIDE;
     b->lastKernel = which;
     if (which == TRM_KERNEL_OCT)
         HIP_TRY(trm::launch_tube_oct(b->c, a, stream));
@@ -518,14 +522,17 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
 struct trm_stream {
     trm_batch *b = nullptr;
     size_t nvoices = 0;
-    DevBuf<float> dState, dFrames, dOut, dMax;
+    DevBuf<float> dState, dFrames, dOut, dMax, dLast, dPushed;
     DevBuf<float> dTube, dHist;       // down-sampling streams: [history | chunk] tube-rate rows; the history between chunks
     DevBuf<uint64_t> dTubeOff, dTubeOff0;
     uint32_t hist = 0;                // tube samples of history a chunk's first output may reach back (multiple of 4)
     DevBuf<uint64_t> dFrameOff, dOutOff;
     DevBuf<uint32_t> dNFrames, dNSamples;
-    std::vector<float> lastFrame;     // [nvoices][16]: the frame the next control period starts from
-    std::vector<float> hostFrames, hostOut;
+    // dLast: [nvoices][16], the frame the next control period starts from; dPushed / dOut: the host-buffer entries' staging
+    std::vector<float> hostOut;
+    std::vector<uint64_t> hFrameOff, hOutOff, hTubeOff0, hTubeOff;      // the index arrays of the current chunk shape
+    std::vector<uint32_t> hNFrames;
+    size_t shapeRows = 0, shapePitch = 0, shapeRowPitch = 0;
     bool haveLast = false;            // an utterance is open
     bool first = true;                // no chunk of it has been synthesized yet
     int mode = TRM_STREAM_MODE_FRAMEWORK;
@@ -552,7 +559,6 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
     if (!s) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_stream"); }
     s->b = b;
     s->nvoices = nvoices;
-    s->lastFrame.assign(nvoices * 16, 0.0f);
     if (!b->c.upsample) {
         s->hist = (2u * (uint32_t)b->d.padSize + 3u) & ~3u;
         if ((rc = s->dHist.reserve(nvoices * s->hist)) || (rc = s->dTubeOff.reserve(nvoices)) || (rc = s->dTubeOff0.reserve(nvoices))) {
@@ -561,7 +567,7 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
             return rc;
         }
     }
-    if ((rc = s->dState.reserve(nvoices * trm::kStreamFloats)) || (rc = s->dFrameOff.reserve(nvoices)) || (rc = s->dOutOff.reserve(nvoices)) ||
+    if ((rc = s->dState.reserve(nvoices * trm::kStreamFloats)) || (rc = s->dLast.reserve(nvoices * 16)) || (rc = s->dFrameOff.reserve(nvoices)) || (rc = s->dOutOff.reserve(nvoices)) ||
         (rc = s->dNFrames.reserve(nvoices)) || (rc = s->dNSamples.reserve(nvoices)) || (rc = s->dMax.reserve(nvoices))) {
         trm_stream_destroy(s);
         return rc;
@@ -614,9 +620,11 @@ size_t trm_stream_samples_for_finish(const trm_stream *s)
     return (size_t)((total * 65536ull + inc - 1) / inc - s->kBase);
 }
 
-// one chunk: `periods` control periods from s->lastFrame through `frames` (nframes rows per voice), or the flush
-static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool flush, float *out, size_t out_pitch,
-                        uint32_t *nout, float *max_out)
+// One chunk on the device: control periods from the stream's last frame through the pushed frames `d_pushed` (device,
+// [nvoices][nframes][16]), or the converter's flush; PCM to d_out (device, voice v at d_out + v * out_pitch).  Everything
+// is work on `st`; nothing here waits for the device.
+static int stream_chunk_device(trm_stream *s, const float *d_pushed, size_t nframes, bool flush, float *d_out, size_t out_pitch,
+                               uint32_t *nout, hipStream_t st)
 {
     trm_batch *b = s->b;
     const size_t V = s->nvoices;
@@ -634,35 +642,44 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
     if (nout) *nout = (uint32_t)count;
     if (s->nBase + N + 2ull * (uint64_t)b->d.padSize + 512 > 0x7FFFFFFFull || kEnd > 0xFFFFFFFFull)
         return fail(TRM_ERANGE, "stream too long");
-    if (count > 0 && (!out || out_pitch < count)) return fail(TRM_EINVAL, "output pitch %zu < %llu samples", out_pitch, (unsigned long long)count);
-    HIP_TRY(hipSetDevice(b->device));
-    hipStream_t st = b->stream;
+    if (count > 0 && (!d_out || out_pitch < count)) return fail(TRM_EINVAL, "output pitch %zu < %llu samples", out_pitch, (unsigned long long)count);
     int rc;
     const bool down = !b->c.upsample;
     const size_t rowPitch = ((size_t)s->hist + (size_t)N + 2u * (size_t)b->d.padSize + 3u) & ~(size_t)3;     // down-sampling streams
-    if ((rc = s->dFrames.reserve(V * rows * 16)) || (rc = s->dOut.reserve(V * (size_t)count + 64))) return rc;
-    s->hostFrames.resize(V * rows * 16);
-    std::vector<uint64_t> foff(V), ooff(V);
-    std::vector<uint32_t> nfr(V, (uint32_t)rows);
-    for (size_t v = 0; v < V; v++) {
-        float *dst = &s->hostFrames[v * rows * 16];
-        size_t r = 0;
-        if (leadRow) { memcpy(dst, s->haveLast ? &s->lastFrame[v * 16] : frames + v * nframes * 16, 16 * sizeof(float)); r = 1; }
-        if (!flush) memcpy(dst + r * 16, frames + v * nframes * 16, nframes * 16 * sizeof(float));
-        foff[v] = v * rows;
-        ooff[v] = v * count;
+    if ((rc = s->dFrames.reserve(V * rows * 16))) return rc;
+    // the rows: [lead row | pushed frames] per voice
+    if (leadRow) {
+        const float *src = s->haveLast ? s->dLast.p : d_pushed;
+        const size_t spitch = s->haveLast ? 16 : nframes * 16;
+        HIP_TRY(hipMemcpy2DAsync(s->dFrames.p, rows * 16 * sizeof(float), src, spitch * sizeof(float), 16 * sizeof(float), V, hipMemcpyDeviceToDevice, st));
     }
-    HIP_TRY(hipMemcpyAsync(s->dFrames.p, s->hostFrames.data(), s->hostFrames.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->dFrameOff.p, foff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->dOutOff.p, ooff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->dNFrames.p, nfr.data(), V * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (!flush)
+        HIP_TRY(hipMemcpy2DAsync(s->dFrames.p + (leadRow ? 16 : 0), rows * 16 * sizeof(float), d_pushed, nframes * 16 * sizeof(float),
+                                 nframes * 16 * sizeof(float), V, hipMemcpyDeviceToDevice, st));
+    // the index arrays depend on the chunk's shape only: uploaded when it changes (host copies live in the stream object)
+    if (s->shapeRows != rows || s->shapePitch != out_pitch || (down && s->shapeRowPitch != rowPitch)) {
+        s->hFrameOff.resize(V); s->hOutOff.resize(V); s->hNFrames.assign(V, (uint32_t)rows);
+        for (size_t v = 0; v < V; v++) { s->hFrameOff[v] = v * rows; s->hOutOff[v] = v * out_pitch; }
+        HIP_TRY(hipStreamSynchronize(st));          // (an earlier launch may still be reading the arrays)
+        HIP_TRY(hipMemcpyAsync(s->dFrameOff.p, s->hFrameOff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->dOutOff.p, s->hOutOff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->dNFrames.p, s->hNFrames.data(), V * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        if (down) {
+            s->hTubeOff0.resize(V); s->hTubeOff.resize(V);
+            for (size_t v = 0; v < V; v++) { s->hTubeOff0[v] = v * rowPitch; s->hTubeOff[v] = v * rowPitch + s->hist; }
+            HIP_TRY(hipMemcpyAsync(s->dTubeOff0.p, s->hTubeOff0.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->dTubeOff.p, s->hTubeOff.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));          // (pageable sources: the copies are done before the vectors can change)
+        s->shapeRows = rows; s->shapePitch = out_pitch; s->shapeRowPitch = rowPitch;
+    }
     if ((rc = ensure_noise(b, (uint32_t)(s->nBase + N) + 2u * (uint32_t)b->d.padSize + 256u, st))) return rc;
     if (N > 0 || flush) {
         trm::TubeArgs a;
         a.frames = s->dFrames.p;
         a.frame_offset = s->dFrameOff.p;
         a.nframes = s->dNFrames.p;
-        a.out = s->dOut.p;
+        a.out = d_out;
         a.out_offset = s->dOutOff.p;
         a.number_samples = s->dNSamples.p;
         a.max_sample = s->dMax.p;
@@ -674,11 +691,6 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
         if (down) {
             // rows of [history | the chunk's tube samples (| the flush zeros)]; the tube stage writes behind the history
             if ((rc = s->dTube.reserve(V * rowPitch + 4))) return rc;
-            std::vector<uint64_t> t0(V), t1(V);
-            for (size_t v = 0; v < V; v++) { t0[v] = v * rowPitch; t1[v] = v * rowPitch + s->hist; }
-            HIP_TRY(hipMemcpyAsync(s->dTubeOff0.p, t0.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(s->dTubeOff.p, t1.data(), V * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));          // t0 / t1 are stack temporaries
             if (s->first) HIP_TRY(hipMemsetAsync(s->dHist.p, 0, V * s->hist * sizeof(float), st));
             HIP_TRY(hipMemcpy2DAsync(s->dTube.p, rowPitch * sizeof(float), s->dHist.p, s->hist * sizeof(float), s->hist * sizeof(float), V,
                                      hipMemcpyDeviceToDevice, st));
@@ -686,9 +698,9 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
             a.tube_offset = s->dTubeOff.p;
         }
         a.nvoices = (uint32_t)V;
-        a.max_nframes = 0xFFFFFFFFu;          // (nframes is this function's own vector)
+        a.max_nframes = 0xFFFFFFFFu;          // (nframes is this function's own array)
         a.stamps = nullptr;
-            a.stream_state = s->dState.p;
+        a.stream_state = s->dState.p;
         a.stream_flags = (s->first ? 1u : 0u) | (flush ? 2u : 0u) | (tract ? 4u : 0u);
         a.stream_n_base = (uint32_t)s->nBase;
         a.stream_k_base = (uint32_t)s->kBase;
@@ -701,7 +713,7 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
                 d.tube = s->dTube.p;
                 d.tube_offset = s->dTubeOff0.p;
                 d.nframes = s->dNFrames.p;
-                d.out = s->dOut.p;
+                d.out = d_out;
                 d.out_offset = s->dOutOff.p;
                 d.number_samples = s->dNSamples.p;
                 d.max_sample = s->dMax.p;
@@ -723,24 +735,61 @@ static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool
             HIP_TRY(hipMemcpy2DAsync(s->dHist.p, s->hist * sizeof(float), s->dTube.p + N, rowPitch * sizeof(float), s->hist * sizeof(float), V,
                                      hipMemcpyDeviceToDevice, st));
         }
+        if (tract && count > 0) {
+            // tube.c:1177 multiplies the tube-rate sample by 100 before its converter; the converter is linear, so the gain
+            // is applied to what it returns (one fp32 rounding of difference)
+            HIP_TRY(trm::launch_gain(d_out, out_pitch, (uint32_t)count, (uint32_t)V, s->dMax.p, 100.0f, st));
+        }
+    } else {
+        HIP_TRY(hipMemsetAsync(s->dMax.p, 0, V * sizeof(float), st));
     }
-    if (count > 0) {
-        s->hostOut.resize(V * (size_t)count);
-        HIP_TRY(hipMemcpyAsync(s->hostOut.data(), s->dOut.p, V * (size_t)count * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (!flush) {
+        // the frame the next control period starts from
+        HIP_TRY(hipMemcpy2DAsync(s->dLast.p, 16 * sizeof(float), d_pushed + (nframes - 1) * 16, nframes * 16 * sizeof(float), 16 * sizeof(float), V,
+                                 hipMemcpyDeviceToDevice, st));
     }
-    std::vector<float> mx(V, 0.0f);
-    if (N > 0 || flush) HIP_TRY(hipMemcpyAsync(mx.data(), s->dMax.p, V * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (tract) {
-        // tube.c:1177 multiplies the tube-rate sample by 100 before its converter; the converter is linear, so the gain is
-        // applied to what it returns (one fp32 rounding of difference)
-        for (size_t i = 0; i < V * (size_t)count; i++) s->hostOut[i] *= 100.0f;
-        for (size_t v = 0; v < V; v++) mx[v] *= 100.0f;
-    }
-    for (size_t v = 0; v < V && count > 0; v++) memcpy(out + v * out_pitch, &s->hostOut[v * (size_t)count], (size_t)count * sizeof(float));
-    if (max_out) memcpy(max_out, mx.data(), V * sizeof(float));
     s->nBase += N;
     s->kBase = kEnd;
+    return TRM_OK;
+}
+
+static void stream_after_push(trm_stream *s) { s->haveLast = true; }
+static void stream_after_finish(trm_stream *s)
+{
+    s->haveLast = false;          // the next push opens a new utterance: tube at rest, converter pre-roll
+    s->first = true;
+    s->nBase = 0;
+    s->kBase = 0;
+}
+
+// host-buffer form: H2D of the frames, the chunk, D2H of its PCM
+static int stream_chunk(trm_stream *s, const float *frames, size_t nframes, bool flush, float *out, size_t out_pitch,
+                        uint32_t *nout, float *max_out)
+{
+    trm_batch *b = s->b;
+    const size_t V = s->nvoices;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = b->stream;
+    int rc;
+    const size_t count = flush ? trm_stream_samples_for_finish(s) : trm_stream_samples_for_push(s, nframes);
+    if (count > 0 && (!out || out_pitch < count)) return fail(TRM_EINVAL, "output pitch %zu < %zu samples", out_pitch, count);
+    if (!flush) {
+        if ((rc = s->dPushed.reserve(V * nframes * 16))) return rc;
+        HIP_TRY(hipMemcpyAsync(s->dPushed.p, frames, V * nframes * 16 * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    if ((rc = s->dOut.reserve(V * count + 64))) return rc;
+    uint32_t got = 0;
+    if ((rc = stream_chunk_device(s, flush ? nullptr : s->dPushed.p, nframes, flush, s->dOut.p, count, &got, st))) return rc;
+    if (nout) *nout = got;
+    if (got > 0) {
+        s->hostOut.resize(V * (size_t)got);
+        HIP_TRY(hipMemcpyAsync(s->hostOut.data(), s->dOut.p, V * (size_t)got * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    std::vector<float> mx(V, 0.0f);
+    HIP_TRY(hipMemcpyAsync(mx.data(), s->dMax.p, V * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t v = 0; v < V && got > 0; v++) memcpy(out + v * out_pitch, &s->hostOut[v * (size_t)got], (size_t)got * sizeof(float));
+    if (max_out) memcpy(max_out, mx.data(), V * sizeof(float));
     return TRM_OK;
 }
 
@@ -749,8 +798,7 @@ int trm_stream_push(trm_stream *s, const float *frames, size_t nframes, float *o
     if (!s || !frames || nframes == 0) return fail(TRM_EINVAL, "null argument / no frames");
     int rc = stream_chunk(s, frames, nframes, false, out, out_pitch, nout, max_out);
     if (rc) return rc;
-    for (size_t v = 0; v < s->nvoices; v++) memcpy(&s->lastFrame[v * 16], frames + (v * nframes + nframes - 1) * 16, 16 * sizeof(float));
-    s->haveLast = true;
+    stream_after_push(s);
     return TRM_OK;
 }
 
@@ -760,10 +808,33 @@ int trm_stream_finish(trm_stream *s, float *out, size_t out_pitch, uint32_t *nou
     if (!s->haveLast) { if (nout) *nout = 0; return TRM_OK; }
     int rc = stream_chunk(s, nullptr, 0, true, out, out_pitch, nout, max_out);
     if (rc) return rc;
-    s->haveLast = false;          // the next push opens a new utterance: tube at rest, converter pre-roll
-    s->first = true;
-    s->nBase = 0;
-    s->kBase = 0;
+    stream_after_finish(s);
+    return TRM_OK;
+}
+
+int trm_stream_push_device(trm_stream *s, const float *d_frames, size_t nframes, float *d_out, size_t out_pitch, uint32_t *nout,
+                           float *d_max_out, void *stream)
+{
+    if (!s || !d_frames || nframes == 0) return fail(TRM_EINVAL, "null argument / no frames");
+    HIP_TRY(hipSetDevice(s->b->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = stream_chunk_device(s, d_frames, nframes, false, d_out, out_pitch, nout, st);
+    if (rc) return rc;
+    if (d_max_out) HIP_TRY(hipMemcpyAsync(d_max_out, s->dMax.p, s->nvoices * sizeof(float), hipMemcpyDeviceToDevice, st));
+    stream_after_push(s);
+    return TRM_OK;
+}
+
+int trm_stream_finish_device(trm_stream *s, float *d_out, size_t out_pitch, uint32_t *nout, float *d_max_out, void *stream)
+{
+    if (!s) return fail(TRM_EINVAL, "null stream");
+    if (!s->haveLast) { if (nout) *nout = 0; return TRM_OK; }
+    HIP_TRY(hipSetDevice(s->b->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = stream_chunk_device(s, nullptr, 0, true, d_out, out_pitch, nout, st);
+    if (rc) return rc;
+    if (d_max_out) HIP_TRY(hipMemcpyAsync(d_max_out, s->dMax.p, s->nvoices * sizeof(float), hipMemcpyDeviceToDevice, st));
+    stream_after_finish(s);
     return TRM_OK;
 }
 

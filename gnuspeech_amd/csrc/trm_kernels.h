@@ -93,6 +93,8 @@ struct DownArgs {
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
+// out[v * pitch + i] *= g (i < count), mx[v] *= g
+hipError_t launch_gain(float *out, size_t pitch, uint32_t count, uint32_t nvoices, float *mx, float g, hipStream_t stream);
 
 // Control-track generation (trm_tracks.hip): event lists -> 16-column frames, one wave per utterance.
 struct TrackArgs {

@@ -597,6 +597,15 @@ __global__ __launch_bounds__(256) void trm_int16_kernel(const ScaleArgs S)
     }
 }
 
+// out[v * pitch + i] *= g for i < count; mx[v] *= g  (streams in TRAcT's loop order: tube.c:1177's x100)
+__global__ __launch_bounds__(256) void trm_gain_kernel(float *out, size_t pitch, uint32_t count, float *mx, float g)
+{
+    float *row = out + (size_t)blockIdx.y * pitch;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) row[i] *= g;
+    if (i == 0 && mx) mx[blockIdx.y] *= g;
+}
+
 // ---------------------------------------------------------------- launchers (host)
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream)
 {
@@ -641,6 +650,13 @@ hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stre
     }
     if (a.stream) return hipErrorInvalidValue;       // (the generic kernel converts whole utterances only)
     hipLaunchKernelGGL(trm_downsample_kernel, dim3(a.nvoices), dim3(256), 0, stream, c, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gain(float *out, size_t pitch, uint32_t count, uint32_t nvoices, float *mx, float g, hipStream_t stream)
+{
+    if (nvoices == 0 || count == 0) return hipSuccess;
+    hipLaunchKernelGGL(trm_gain_kernel, dim3((count + 255) / 256, nvoices), dim3(256), 0, stream, out, pitch, count, mx, g);
     return hipGetLastError();
 }
 

@@ -48,6 +48,15 @@ constexpr int kQRoles = 6;           // osc, mix, coef x2 (area | frication), tu
 constexpr int kKPitch = 2 * kWave + 4;   // coef -> tube: float4s per (buffer, sample): {kk | tp} x the tube wave's 64 lanes,
                                          // + 64 bytes so that the writers' four time slots fall in different LDS banks
 constexpr int kXPitch = kQV + 4;         // mix / coef -> tube: float4s per (buffer, sample) of the per-voice records, same idea
+// One-shot instances: the control frames are staged in LDS by LDS-DMA (the area wave, which has no other vector-memory
+// traffic: one 1 KB transfer per control period = 16 voices x 64 bytes) and read by the three waves that turn them into
+// tracks when a period starts -- see trm_oct.hip.  Frame f lives in slot f % 4: when the oscillator wave enters the
+// period between frames p and p+1, the stager retires the transfer of frame p+2 (sent for a period earlier) and, one
+// step later -- when the lagging coefficient waves are through with frame p-1 --, sends for frame p+3 in its place.  A
+// control period must hold three steps (launch_tube_quad).  Carrying the prefetched frames in registers costs every
+// coefficient wave ~30 register-to-register copies per step (the streaming instance, which must also run control periods
+// of a few samples, still does).
+constexpr int kQFrameRing = 4;
 // kStream: the launch is a chunk of a streamed utterance (state restored / saved); a compile-time switch so that
 // the one-shot instance carries none of it.
 // LDS layout of one workgroup, carved out of ONE dynamically sized array: with static __shared__ arrays the compiler
@@ -70,7 +79,8 @@ struct QuadLds {
     static constexpr size_t oMx = oInfo + sizeof(uint4) * kQV;                            // float  [8 * kWave]
     static constexpr size_t oNoise = oMx + sizeof(float) * 8 * kWave;                     // float  [kNoiseRing]
     static constexpr size_t oSync = oNoise + sizeof(float) * kNoiseRing;                  // uint32 [2]
-    static constexpr size_t kBytes = oSync + 16;
+    static constexpr size_t oFrames = oSync + 16;                                         // float4 [kQFrameRing * kQV * 4] (one-shot instances)
+    static constexpr size_t kBytes = oFrames + sizeof(float4) * kQFrameRing * kQV * 4;
     static_assert(oA % 16 == 0 && oX % 16 == 0 && oBP % 16 == 0 && oK % 16 == 0 && oY % 16 == 0 && oRows % 16 == 0 && oInfo % 16 == 0, "16-byte aligned pieces");
 };
 
@@ -93,6 +103,8 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     float *const sMx = reinterpret_cast<float *>(sLds + L::oMx);
     float *const sNoise = reinterpret_cast<float *>(sLds + L::oNoise);
     uint32_t *const sRowSync = reinterpret_cast<uint32_t *>(sLds + L::oSync);   // [0] convert -> mix: first block whose staged rows are still needed; [1] mix -> convert: blocks staged
+    float4 *const sF = reinterpret_cast<float4 *>(sLds + L::oFrames);          // control frames [f % kQFrameRing][voice][quarter]
+    constexpr bool kLdsFrames = !kStream;
 
     constexpr int kStampRoles = kQRoles;
     (void)kStampRoles;
@@ -137,10 +149,34 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
     auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
+    // staged frames (kLdsFrames): this lane's voice's frame f (nominal index: past the voice's last frame the stager
+    // repeats it), `quads` 16-byte quarters of it
+    auto frame_to = [&](uint32_t f, float *dst, int quads) {
+        for (int q = 0; q < quads; q++) {
+            const float4 x = sF[((f % kQFrameRing) * kQV + vq) * 4 + q];
+            dst[4 * q] = x.x; dst[4 * q + 1] = x.y; dst[4 * q + 2] = x.z; dst[4 * q + 3] = x.w;
+        }
+    };
+    // the stager (area wave): lane -> (voice lane / 4, quarter lane % 4) of the workgroup's 16 frames
+    const float *stageSrc = nullptr;
+    uint32_t stageNfr = 0;
+    if (kLdsFrames && role == 2) {
+        const uint32_t sv = min(blockIdx.x * kQV + ((uint32_t)lane >> 2), A.nvoices - 1);
+        stageNfr = min(A.nframes[sv], A.max_nframes);
+        stageSrc = A.frames + (stageNfr > 0 ? A.frame_offset[sv] * 16 : 0) + (lane & 3) * 4;
+    }
+    auto stage_frame = [&](uint32_t f) {
+        const uint32_t fi = stageNfr > 0 ? (f < stageNfr ? f : stageNfr - 1) : 0u;
+        dma16(stageSrc + (size_t)fi * 16, reinterpret_cast<float *>(&sF[(f % kQFrameRing) * kQV * 4]));
+    };
 
     for (int i = threadIdx.x; i < kQV * kYStride; i += kWave * kQRoles) sY[i] = 0.0f;
     for (int i = threadIdx.x; i < kQV * kOStride; i += kWave * kQRoles) sO[i] = make_float2(0.0f, 0.0f);
     if (threadIdx.x < 2) sRowSync[threadIdx.x] = 0u;
+    if (kLdsFrames && role == 2 && nSteps > 0) {
+        stage_frame(0); stage_frame(1); stage_frame(2); stage_frame(3);
+        dma_wait_all();
+    }
     if (streaming && !sFirst) {
         // the last 32 tube samples of the previous chunk: positions -32 .. -1 of this chunk's rings
         __syncthreads();
@@ -225,14 +261,21 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         OscSlotTrack T;
         double P = 0.0;                                 // oscillator position at the start of the block
         if (streaming && !sFirst) P = *reinterpret_cast<const double *>(st);
-        float prev[4], cur[4], nxt[4];
+        float prev[4], cur[4], nxt[4];                  // (streaming instance: the frames carried in registers)
         uint32_t per = 0, j = (uint32_t)part;           // control period / position in it of this lane's sample
         if (nSteps > 0) {
-            load_frame(frames, frame_index(0), prev, 1);
-            load_frame(frames, frame_index(1), cur, 1);
-            load_frame(frames, frame_index(2), nxt, 1);
-            if (sHold) for (int q = 0; q < 4; q++) prev[q] = cur[q];
-            osc_slot_setup(T, C, prev, cur, (int)j);
+            if constexpr (kLdsFrames) {
+                float fa[4], fb[4];
+                frame_to(0, fa, 1);
+                frame_to(1, fb, 1);
+                osc_slot_setup(T, C, fa, fb, (int)j);
+            } else {
+                load_frame(frames, frame_index(0), prev, 1);
+                load_frame(frames, frame_index(1), cur, 1);
+                load_frame(frames, frame_index(2), nxt, 1);
+                if (sHold) for (int q = 0; q < 4; q++) prev[q] = cur[q];
+                osc_slot_setup(T, C, prev, cur, (int)j);
+            }
         }
         float2 *const ring = &sO[vq * kOStride];
         ScanState Z;
@@ -257,9 +300,16 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 if (j >= CP) {      // this lane's sample starts a control period (:289); the next frame was prefetched
                     j -= CP;
                     per++;
-                    for (int q = 0; q < 4; q++) { prev[q] = sHold ? nxt[q] : cur[q]; cur[q] = nxt[q]; }
-                    load_frame(frames, frame_index(per + 2), nxt, 1);
-                    osc_slot_setup(T, C, prev, cur, (int)j);
+                    if constexpr (kLdsFrames) {
+                        float fa[4], fb[4];
+                        frame_to(per, fa, 1);
+                        frame_to(per + 1, fb, 1);
+                        osc_slot_setup(T, C, fa, fb, (int)j);
+                    } else {
+                        for (int q = 0; q < 4; q++) { prev[q] = sHold ? nxt[q] : cur[q]; cur[q] = nxt[q]; }
+                        load_frame(frames, frame_index(per + 2), nxt, 1);
+                        osc_slot_setup(T, C, prev, cur, (int)j);
+                    }
                 }
                 const double db = __builtin_fma((double)j, T.glotDelta, T.glot0);
                 double axd = db >= 60.0 ? 1.0 : T.axGeo;      // amplitude() with its clamps (:294-296)
@@ -399,18 +449,37 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         ScanState Z;
         scans_restore(Z, !area, false);
         CoefTrack T;
-        float prev[16], cur[16], nxt[16];
+        float prev[16], cur[16], nxt[16];               // (streaming instance only)
         uint32_t per = 0, j = (uint32_t)part;
         if (nSteps > 0) {
-            load_frame(frames, frame_index(0), prev, 4);
-            load_frame(frames, frame_index(1), cur, 4);
-            load_frame(frames, frame_index(2), nxt, 4);
-            if (sHold) for (int q = 0; q < 16; q++) prev[q] = cur[q];
-            coef_track_setup(T, C, prev, cur);
+            if constexpr (kLdsFrames) {
+                float fa[16], fb[16];
+                frame_to(0, fa, 4);
+                frame_to(1, fb, 4);
+                coef_track_setup(T, C, fa, fb);
+            } else {
+                load_frame(frames, frame_index(0), prev, 4);
+                load_frame(frames, frame_index(1), cur, 4);
+                load_frame(frames, frame_index(2), nxt, 4);
+                if (sHold) for (int q = 0; q < 16; q++) prev[q] = cur[q];
+                coef_track_setup(T, C, prev, cur);
+            }
         }
+        // the stager (area wave of a one-shot instance): the oscillator wave, two steps ahead of this one, enters the
+        // period between frames p and p + 1 in the step that holds sample p * CP
+        uint32_t stP = 1, stBnd = CP, stSend = 0;
         STAMP_DECL
         for (uint32_t step = 0; step < nSteps; step++) {
             STAMP_BEGIN
+            if (kLdsFrames && area) {
+                if (stSend) { stage_frame(stSend); stSend = 0; }
+                if (step * kStepN < nTotal && step * kStepN + (kStepN - 1) >= stBnd) {
+                    dma_wait_all();              // frame stP + 2, sent for a period ago
+                    stSend = stP + 3;            // its slot is frame stP - 1's: free from the next step on
+                    stP++;
+                    stBnd += CP;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < kSub; u++) {
               const uint32_t blk = (step - 2) * kSub + u;
@@ -419,9 +488,16 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 if (j >= CP) {
                     j -= CP;
                     per++;
-                    for (int q = 0; q < 16; q++) { prev[q] = sHold ? nxt[q] : cur[q]; cur[q] = nxt[q]; }
-                    load_frame(frames, frame_index(per + 2), nxt, 4);
-                    coef_track_setup(T, C, prev, cur);
+                    if constexpr (kLdsFrames) {
+                        float fa[16], fb[16];
+                        frame_to(per, fa, 4);
+                        frame_to(per + 1, fb, 4);
+                        coef_track_setup(T, C, fa, fb);
+                    } else {
+                        for (int q = 0; q < 16; q++) { prev[q] = sHold ? nxt[q] : cur[q]; cur[q] = nxt[q]; }
+                        load_frame(frames, frame_index(per + 2), nxt, 4);
+                        coef_track_setup(T, C, prev, cur);
+                    }
                 }
                 Coefs K;
                 PartRecord R[4];
@@ -449,6 +525,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             STAMP_END
         }
         STAMP_STORE(role)
+        if (kLdsFrames && area) dma_wait_all();     // nothing may still be writing LDS when the wave ends
     } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
         // the only serial role: where it shares a SIMD (two workgroups on a CU) its instructions go first (8192 voices:
@@ -714,6 +791,10 @@ hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t strea
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kQV - 1) / kQV;
     if (a.stream_state) return launch_instance<true, 2>(c, a, stream, grid);
+    // one-shot instances stage the control frames in a ring of four: frame p+3 replaces frame p-1 one step into period p,
+    // and the coefficient waves' last lanes read frame p-1 three steps into period p-1 -- a period must hold three steps
+    // of up to 8 samples (the caller runs trm_kernels.hip's kernel otherwise)
+    if (c.controlPeriod < 24) return hipErrorInvalidValue;
     if (cus > 0 && grid > (uint32_t)cus) return launch_instance<false, 1>(c, a, stream, grid);
     return launch_instance<false, 2>(c, a, stream, grid);
 }

@@ -54,3 +54,30 @@ class TRMStream:
         check(call(out.ctypes.data, C.byref(n), mx.ctypes.data))
         assert n.value == m
         return out[:, :m], mx
+
+    # ---- device-buffer forms (torch tensors on the stream's device; asynchronous on torch's current stream)
+    def push_device(self, frames, out=None, max_out=None):
+        """frames: float32 CUDA tensor [nvoices, n, 16].  Returns (pcm [nvoices, m] view of `out`, m): nothing crosses PCIe,
+        nothing is waited for.  `out` (optional) = a float32 CUDA tensor [nvoices, pitch >= m] to write into."""
+        import torch
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous() and frames.shape[0] == self.nvoices and frames.shape[2] == 16
+        m = lib().trm_stream_samples_for_push(self._h, frames.shape[1])
+        return self._run_device(lambda o, pitch, n, mx, st: lib().trm_stream_push_device(self._h, frames.data_ptr(), frames.shape[1], o, pitch, n, mx, st),
+                                m, frames.device, out, max_out)
+
+    def finish_device(self, device=None, out=None, max_out=None):
+        import torch
+        m = lib().trm_stream_samples_for_finish(self._h)
+        dev = out.device if out is not None else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        return self._run_device(lambda o, pitch, n, mx, st: lib().trm_stream_finish_device(self._h, o, pitch, n, mx, st), m, dev, out, max_out)
+
+    def _run_device(self, call, m, device, out, max_out):
+        import torch
+        if out is None:
+            out = torch.empty((self.nvoices, max(m, 1)), dtype=torch.float32, device=device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.shape[0] == self.nvoices and out.stride(1) == 1 and out.shape[1] >= m
+        n = C.c_uint32()
+        st = torch.cuda.current_stream(device).cuda_stream
+        check(call(out.data_ptr(), out.stride(0), C.byref(n), max_out.data_ptr() if max_out is not None else None, st))
+        assert n.value == m
+        return out[:, :m], m

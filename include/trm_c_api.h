@@ -337,15 +337,27 @@ int  trm_stream_push(trm_stream *stream, const float *frames, size_t nframes, fl
  * can then start a new utterance with its next push. */
 int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_t *nout, float *max_out);
 
+/* Device-buffer forms: d_frames fp32 [nvoices][nframes][16] and d_out fp32 [nvoices][out_pitch] are HIP device pointers on
+ * the stream's device, d_max_out (optional) fp32 [nvoices]; the calls are asynchronous on `stream` (a hipStream_t or NULL)
+ * and nothing crosses PCIe -- what a server that mixes, encodes or plays the voices on the device uses, and what the
+ * number of concurrent real-time voices is measured with (tools/realtime_voices.py): PCM returned to the host costs
+ * 88-176 KB per voice-second, so PCIe (not the kernel) bounds a host-returning stream at ~0.3-0.6 M voices per GPU.
+ * *nout is known on return (it depends on the frame count only).  Host- and device-buffer calls of one stream may be mixed. */
+int  trm_stream_push_device(trm_stream *stream, const float *d_frames, size_t nframes, float *d_out, size_t out_pitch,
+                            uint32_t *nout, float *d_max_out, void *hip_stream);
+int  trm_stream_finish_device(trm_stream *stream, float *d_out, size_t out_pitch, uint32_t *nout, float *d_max_out,
+                              void *hip_stream);
+
 /* Kernel form of the synthesis launch.  All forms compute the same samples (same arithmetic per value);
  * they differ in how a voice is laid out on the machine:
  *   TRM_KERNEL_WIDE  one voice per lane, 64 voices per workgroup: highest throughput once the batch fills
  *                    the chip (AUTO: above 32 voices per CU, 8192 on MI355X);
  *   TRM_KERNEL_QUAD  four lanes per voice, 16 voices per workgroup: mid-size batches (AUTO: above 16 voices per CU)
- *                    and every stream (trm_stream_*);
+ *                    and every stream (trm_stream_*).  One-shot batches need a control period of at least 24 tube
+ *                    samples (the control frames are staged in LDS a period ahead); TRM_KERNEL_WIDE runs otherwise;
  *   TRM_KERNEL_OCT   eight lanes per voice, 8 voices per workgroup, two workgroups per CU: lowest latency for
  *                    batches of up to 16 voices per CU (4096 on MI355X).  Needs a control period of at least 16 tube
- *                    samples; where it does not apply (longer batches, shorter periods) TRM_KERNEL_QUAD runs instead.
+ *                    samples; longer batches run TRM_KERNEL_QUAD, shorter periods TRM_KERNEL_WIDE instead.
  * TRM_KERNEL_AUTO (default) picks by batch size; the environment variable TRM_TUBE_KERNEL=wide|quad|oct
  * overrides AUTO (diagnostics).  Parameters with more than four output samples per tube sample (96 kHz output)
  * always run TRM_KERNEL_WIDE.  No reference counterpart: the reference runs one tube per thread. */

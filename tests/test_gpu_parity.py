@@ -197,10 +197,10 @@ def test_very_high_rate_ratio_runs_the_lane_form(g, form):
 
 
 def test_eight_lane_form_runs_where_it_applies(g, monkeypatch):
-    """TRM_KERNEL_OCT (include/trm_c_api.h): AUTO's choice for batches of up to two 8-voice workgroups per CU; a control
-    period below 16 tube samples (its feed-forward lanes step 8 samples at a time and set a period up while the lanes of
-    the one before still cross into it) or a longer batch runs the four-lane form instead, whatever was asked for -- with
-    the same result against the oracle."""
+    """TRM_KERNEL_OCT (include/trm_c_api.h): AUTO's choice for batches of up to two 8-voice workgroups per CU; a longer
+    batch runs the four-lane form instead, and control periods too short for a form's frame staging (below 16 tube
+    samples with eight lanes, below 24 with four: the one-shot kernels keep the control frames in LDS a period ahead)
+    run the one-voice-per-lane form, whatever was asked for -- with the same result against the oracle."""
     monkeypatch.delenv("TRM_TUBE_KERNEL", raising=False)
     monkeypatch.delenv("TRM_QUAD_CUS", raising=False)
     rows = cases.load_gnuspeech_rows()
@@ -215,14 +215,28 @@ def test_eight_lane_form_runs_where_it_applies(g, monkeypatch):
     assert b.derived["controlPeriod"] < 16
     b.set_kernel("oct")
     b.synthesize(voices)
-    assert b.last_kernel == "quad"
+    assert b.last_kernel == "wide"
     _batch_vs_oracle(g, pd, voices)
-    pd["length"] = 20.0                                 # control period 18: two steps fit
+    pd["length"] = 20.0                                 # control period 18: two eight-sample steps fit
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
     assert 16 <= b.derived["controlPeriod"] < 24
     b.synthesize(voices)
     assert b.last_kernel == "oct"
     _batch_vs_oracle(g, pd, voices)
+    b.set_kernel("quad")                                # ... but not the four-lane form's three steps
+    b.synthesize(voices)
+    assert b.last_kernel == "wide"
+    pd["length"] = 14.0                                 # control period 25: every form runs
+    for form in ("oct", "quad", "wide"):
+        b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+        assert 24 <= b.derived["controlPeriod"] < 32
+        b.set_kernel(form)
+        pcm, ns, mx = b.synthesize(voices)
+        assert b.last_kernel == form
+        op = O.InputParams.from_dict(pd)
+        for v, fr in enumerate(voices):
+            o = O.synthesize(op, np.asarray(fr, dtype=np.float32).astype(np.float64))
+            assert int(ns[v]) == o["numberSamples"] and nrms(pcm[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL, (form, v)
     monkeypatch.setenv("TRM_QUAD_CUS", "1")             # (read at create: a "device" of one CU holds 16 voices in this form)
     b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params(44100.0)))
     b.synthesize([rows[:30].copy()] * 16)

@@ -217,3 +217,43 @@ def test_tract_mode_stream_matches_oracle(g, rate, seed):
         s2.set_mode("tract")
     s2.finish()
     s2.set_mode("tract")
+
+
+@pytest.mark.parametrize("rate,mode", [(44100.0, "framework"), (16000.0, "framework"), (44100.0, "tract")])
+def test_device_buffer_entries_equal_the_host_entries(g, rate, mode):
+    """trm_stream_push_device / _finish_device (frames and PCM stay on the device, asynchronous, nothing crosses PCIe) return
+    the host entries' samples bit for bit -- both converter branches, both loop orders, uneven chunks, into a caller's
+    buffer with a pitch of its own; and host and device calls of one stream mix."""
+    import torch
+    pd = cases.monet_default_params(rate)
+    V, n = 19, 30
+    fr = cases.config3_frames(V, nframes=n, seed=20250411).astype(np.float32)
+    chunks = [1, 7, 2, 20]
+    want, want_max, _ = None, None, None
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=V, mode=mode)
+    parts, at = [], 0
+    for c in chunks:
+        parts.append(s.push(fr[:, at:at + c])[0]); at += c
+    parts.append(s.finish()[0])
+    want = np.concatenate(parts, axis=1)
+    d = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=V, mode=mode)
+    dev = torch.device("cuda", 0)
+    frd = torch.from_numpy(fr).to(dev)
+    big = torch.zeros((V, want.shape[1] + 77), dtype=torch.float32, device=dev)       # the caller's own buffer and pitch
+    mx = torch.zeros(V, dtype=torch.float32, device=dev)
+    got, at, pos = [], 0, 0
+    for i, c in enumerate(chunks):
+        if i == 2:                                  # a host-buffer call in the middle of device-buffer ones
+            o = d.push(fr[:, at:at + c])[0]
+            big[:, pos:pos + o.shape[1]] = torch.from_numpy(o).to(dev)
+            m = o.shape[1]
+        else:
+            _, m = d.push_device(frd[:, at:at + c].contiguous(), out=big[:, pos:], max_out=mx)
+        at += c
+        pos += m
+    _, m = d.finish_device(out=big[:, pos:], max_out=mx)
+    pos += m
+    torch.cuda.synchronize()
+    assert pos == want.shape[1]
+    assert np.array_equal(big[:, :pos].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert float(big[:, pos:].abs().max()) == 0.0                                      # nothing written past the samples
