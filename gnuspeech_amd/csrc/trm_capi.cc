@@ -536,6 +536,7 @@ struct trm_stream {
     bool haveLast = false;            // an utterance is open
     bool first = true;                // no chunk of it has been synthesized yet
     int mode = TRM_STREAM_MODE_FRAMEWORK;
+    bool wide = false;                // trm_kernels.hip's streaming instance (one voice per lane) instead of trm_quad.hip's
     uint64_t nBase = 0, kBase = 0;    // tube samples synthesized / converter outputs emitted so far
 };
 
@@ -551,14 +552,16 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
         trm_batch_destroy(b);
         return fail(TRM_ERANGE, "streaming: output rate too far below the tube rate (%d Hz) for the tiled down-sampling kernel", b->d.sampleRate);
     }
-    if (quad_ratio_too_high(b->c)) {
-        trm_batch_destroy(b);
-        return fail(TRM_ERANGE, "streaming: more than four outputs per tube sample (tube rate %d Hz): the four-lane kernel form that carries streams does not convert that", b->d.sampleRate);
-    }
     trm_stream *s = new (std::nothrow) trm_stream();
     if (!s) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_stream"); }
     s->b = b;
     s->nvoices = nvoices;
+    // The kernel form is the stream's for life (the saved state is laid out for it): one voice per lane once the voices
+    // fill the chip (and for what the four-lane form does not convert: more than four outputs per tube sample), four
+    // lanes per voice below that.  TRM_TUBE_KERNEL=wide|quad overrides (diagnostics).
+    s->wide = nvoices >= (size_t)b->wideThreshold || quad_ratio_too_high(b->c);
+    if (b->envKernel == TRM_KERNEL_WIDE) s->wide = true;
+    if (b->envKernel == TRM_KERNEL_QUAD && !quad_ratio_too_high(b->c)) s->wide = false;
     if (!b->c.upsample) {
         s->hist = (2u * (uint32_t)b->d.padSize + 3u) & ~3u;
         if ((rc = s->dHist.reserve(nvoices * s->hist)) || (rc = s->dTubeOff.reserve(nvoices)) || (rc = s->dTubeOff0.reserve(nvoices))) {
@@ -603,6 +606,7 @@ int trm_stream_set_mode(trm_stream *s, int mode)
 }
 
 int trm_stream_mode(const trm_stream *s) { return s ? s->mode : TRM_STREAM_MODE_FRAMEWORK; }
+int trm_stream_kernel(const trm_stream *s) { return s ? (s->wide ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD) : TRM_KERNEL_AUTO; }
 
 size_t trm_stream_samples_for_push(const trm_stream *s, size_t nframes)
 {
@@ -705,7 +709,9 @@ static int stream_chunk_device(trm_stream *s, const float *d_pushed, size_t nfra
         a.stream_n_base = (uint32_t)s->nBase;
         a.stream_k_base = (uint32_t)s->kBase;
         a.stream_k_end = (uint32_t)kEnd;
-        HIP_TRY(trm::launch_tube_quad(b->c, a, st, b->cus));
+        if (s->wide) HIP_TRY(trm::launch_tube(b->c, a, st));
+        else HIP_TRY(trm::launch_tube_quad(b->c, a, st, b->cus));
+        b->lastKernel = s->wide ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD;
         s->first = false;
         if (down) {
             if (count > 0) {

@@ -65,6 +65,12 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 //     straight from registers as two contiguous 128-byte pieces of PCM -- no transposition tile, no
 //     per-output control flow.  The two convert waves take alternate row pairs; a fixed number of
 //     rows per step keeps them ahead of production.
+// kStream: the launch is one chunk of a streamed utterance (trm_kernels.h: state restored at its start, saved at its last
+// tube sample; converter outputs keep their global index, ring positions follow the global tube-sample index); a
+// compile-time switch so that the one-shot instance carries none of it.  Per voice kStreamFloats floats of state:
+//   [0..1] oscillator position (fp64)   [2..25] the FIR's partial sums   [26..57] the 32 travelling waves
+//   [58..68] filter memories            [72..103] the last 32 tube samples (the converter's history)
+template <bool kStream>
 __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float4 sW[2 * kTB * kWave];          // osc -> mix: {wa, wb, ax, ah1}
@@ -99,7 +105,11 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     // (nfrMax-1) control periods, then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93).
     // Lanes whose utterance is shorter than the group's longest keep stepping on their last frame;
     // the tube stage hands zeros to the converter past a voice's own end.
-    const uint32_t nTotal = nfrMax > 0 ? ntubeMax + 2u * (uint32_t)C.padSize : 0;
+    const bool sFirst = !kStream || (A.stream_flags & 1u), sLast = !kStream || (A.stream_flags & 2u);
+    const bool sHold = kStream && (A.stream_flags & 4u);       // TRAcT's loop order: a period runs on the frame that ends it, held
+    const uint32_t nBase = kStream ? A.stream_n_base : 0u, kBase = kStream ? A.stream_k_base : 0u;
+    float *const st = kStream ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
+    const uint32_t nTotal = nfrMax > 0 ? ntubeMax + (sLast ? 2u * (uint32_t)C.padSize : 0u) : 0;
     // Output rows (64 lanes) a step's kTB tube samples turn into: kTB * 2^16/inc; the convert waves get
     // strictly more than that per step, in row pairs, split between the two waves.
     // the last tube block is written at step ceil(nTotal/kTB), readable one step later; the convert waves
@@ -112,6 +122,18 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
 
     for (int i = threadIdx.x; i < kWave * kYStride; i += kWave * kRoles) sY[i] = 0.0f;   // 25 zeros of pre-roll
+    if (kStream && !sFirst) {
+        // the last 32 tube samples of the chunks before this one, at their places in the ring (global sample G at slot G + 25)
+        __syncthreads();
+        for (int i = threadIdx.x; i < kWave * 32; i += kWave * kRoles) {
+            const int q = i >> 5, t = i & 31;
+            const uint32_t vv = blockIdx.x * kWave + q < A.nvoices ? blockIdx.x * kWave + q : A.nvoices - 1;
+            const float y = A.stream_state[(size_t)vv * kStreamFloats + 72 + t];
+            const uint32_t slot = (nBase - 32u + (uint32_t)t + (kSrcWindow - 1)) & (kYRing - 1);
+            sY[q * kYStride + slot] = y;
+            if (slot < (uint32_t)kYMirror) sY[q * kYStride + slot + kYRing] = y;
+        }
+    }
     __syncthreads();
 
     if (role == 0) {
@@ -119,7 +141,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         auto sine = [&](int i) { return sine_table(i); };
         OscState S;
         ExciteTrack T;
-        S.oscPos = 0.0;
+        S.oscPos = (kStream && !sFirst) ? *reinterpret_cast<const double *>(st) : 0.0;
         // (both frames of a control period are fetched when it starts, once per ~80 samples: carrying the current frame
         // to the next boundary in registers costs a register-to-register copy of it per STEP, the loop's phi nodes)
         auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
@@ -135,11 +157,12 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         j = 0;
                         f++;
                         float prev[4], cur[4];
-                        load_frame(frames, frame_at(f - 1), prev, 1);
+                        load_frame(frames, frame_at(sHold ? f : f - 1), prev, 1);
                         load_frame(frames, frame_at(f), cur, 1);
                         excite_track_setup(T, C, prev, cur);
                     }
                     OscOut O = osc_sample(S, T, C, (int)j, sine);
+                    if (kStream && n + 1u == ntubeLane && laneValid) *reinterpret_cast<double *>(st) = S.oscPos;   // the chunk's last sample
                     j++;
                     sW[(buf * kTB + u) * kWave + lane] = make_float4(O.wa, O.wb, O.ax, O.ah1);
                 }
@@ -155,7 +178,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
         };
         FirState S;
-        for (int i = 0; i < 24; i++) S.fir[i] = 0.f;
+        for (int i = 0; i < 24; i++) S.fir[i] = (kStream && !sFirst) ? st[2 + i] : 0.f;
         // The 25 distinct FIR taps live in VGPRs of this wave (uniform values): as SGPRs they would
         // exceed the scalar file together with the other constants and be spilled to VGPR lanes.
         float firv[kFirUnique];
@@ -183,6 +206,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                         OscOut O;
                         O.wa = w.x; O.wb = w.y; O.ax = w.z; O.ah1 = w.w;
                         Excitation E = mix_sample(S, C, firv, O, sNoise[n & (kNoiseRing - 1)]);
+                        if (kStream && n + 1u == ntubeLane && laneValid)
+                            for (int i = 0; i < 24; i++) st[2 + i] = S.fir[i];
                         sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
                     }
                 }
@@ -210,11 +235,11 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
                     j -= CP;
                     f++;
                     float prev[16], cur[16];       // (fetched per period, not carried: see the oscillator wave)
-                    load_frame(frames, frame_at(f - 1), prev, 4);
+                    load_frame(frames, frame_at(sHold ? f : f - 1), prev, 4);
                     load_frame(frames, frame_at(f), cur, 4);
                     coef_track_setup(T, C, prev, cur);
                 }
-                Coefs K = coef_sample(T, C, (int)j);
+                Coefs K = coef_sample<kStream>(T, C, (int)j);
                 j += kTB;
                 // 20 floats per sample: C8, alphaLR and bpAlpha are re-derived by the tube wave (1 op each)
                 float4 *dst = &sK[((buf * kTB + u) * kKQuads) * kWave + lane];
@@ -238,6 +263,12 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         waves_reset(wA);
         waves_reset(wB);
         filters_reset(F);
+        if (kStream && !sFirst) {
+            for (int i = 0; i < 10; i++) { wA.oT[i] = st[26 + i]; wA.oB[i] = st[36 + i]; }
+            for (int i = 0; i < 6; i++) { wA.nT[i] = st[46 + i]; wA.nB[i] = st[52 + i]; }
+            F.mReflY = st[58]; F.mRadX = st[59]; F.mRadY = st[60]; F.nReflY = st[61]; F.nRadX = st[62]; F.nRadY = st[63];
+            F.throatY = st[64]; F.bpX1 = st[65]; F.bpX2 = st[66]; F.bpY1 = st[67]; F.bpY2 = st[68];
+        }
         // the step's constants as vector registers (tube_step): opaque moves, so that the compiler cannot go back to the
         // kernel arguments' scalar registers.  (With the other round-3 changes 18.2 ms against 18.5 ms for the saturating
         // batch, profiles/ab_r03.txt; on the round-2 kernel alone the same change measured 1 % slower.)
@@ -272,12 +303,19 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
             K.pad_ = 0.0f;
             float y = tube_step(o, nw, F, TC, E, K);
+            if (kStream && n + 1u == ntubeLane && laneValid) {       // the chunk's last sample: what the next chunk starts from
+                for (int i = 0; i < 10; i++) { st[26 + i] = nw.oT[i]; st[36 + i] = nw.oB[i]; }
+                for (int i = 0; i < 6; i++) { st[46 + i] = nw.nT[i]; st[52 + i] = nw.nB[i]; }
+                st[58] = F.mReflY; st[59] = F.mRadX; st[60] = F.mRadY; st[61] = F.nReflY; st[62] = F.nRadX; st[63] = F.nRadY;
+                st[64] = F.throatY; st[65] = F.bpX1; st[66] = F.bpX2; st[67] = F.bpY1; st[68] = F.bpY2;
+            }
             y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
-            // converter position of tube sample n is n + 25 (25 zeros of pre-roll)
-            const uint32_t slot = (n + (kSrcWindow - 1)) & (kYRing - 1);
+            // converter position of tube sample n is n + 25 (25 zeros of pre-roll); a chunk's sample n is the
+            // utterance's sample nBase + n
+            const uint32_t slot = (nBase + n + (kSrcWindow - 1)) & (kYRing - 1);
             ring[slot] = y;
             if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;   // mirror: windows never wrap
-            if (tubeOut && laneValid && n < ntubeLane + 2u * (uint32_t)C.padSize) tubeOut[n] = y;
+            if (tubeOut && laneValid && n < ntubeLane + (sLast ? 2u * (uint32_t)C.padSize : 0u)) tubeOut[n] = y;
         };
         static_assert(kTB == 2, "the tube stage ping-pongs two wave sets per step");
         STAMP_DECL
@@ -296,14 +334,21 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             STAMP_END
         }
         STAMP_STORE(role)
+        if (kStream && laneValid && ntubeLane > 0) {
+            // the last 32 tube samples so far (older ones than the chunk's are still in the ring, where the start put them)
+            for (int t = 0; t < 32; t++) st[72 + t] = ring[(nBase + ntubeLane - 32u + (uint32_t)t + (kSrcWindow - 1)) & (kYRing - 1)];
+        }
     } else {
         // ------------------------------------------------------------ convert (lane = output time)
         const int cw = role - 5;                    // this wave converts voices 32*cw .. 32*cw+31
+        // outputs of this launch per voice: the utterance's (TRMSampleRateConverter.m:160-173); a chunk's: global indices
+        // kBase <= k < stream_k_end, the same for every voice
         uint32_t noutLane = 0;
         if (nfr > 0) {
             uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
             noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
         }
+        if (kStream) noutLane = A.stream_k_end - kBase;
         if (!laneValid) noutLane = 0;
         // per-voice values stay in the VGPRs of lane == voice and are broadcast per row with v_readlane
         const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v]);
@@ -328,7 +373,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         // (26 + 6 zeros) with 4 zeros in front of row 0, so the shifted fetch only ever picks up zeros.
         v2f cc[16];
         auto fetch_row = [&](uint32_t blk) {
-            const uint32_t k = blk * kCvtCols + col;
+            const uint32_t k = kBase + blk * kCvtCols + col;
             const uint32_t off = src_position(k, inc) & 3u;
             const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
             // (the loads land while the wave idles until its next metered pair)
@@ -336,17 +381,17 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         };
         uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..7) of block `blk`: voices 32*cw + 4*pr .. +3
         uint32_t winBase = 0;           // this lane's aligned window start inside a voice's ring (floats)
-        uint32_t kLane = 0;             // this lane's output index
+        uint32_t kLane = 0;             // this lane's output index (within the launch; + kBase: within the utterance)
         uint32_t needLast = 0;          // last tube sample the current block reads (uniform)
         uint32_t needNext = 0;          // ... and the one after it: complete already = this wave is a block behind
         auto begin_block = [&]() {
             kLane = blk * kCvtCols + col;
-            winBase = src_position(kLane, inc) & (kYRing - 1) & ~3u;
-            // highest tube sample the block reads: the window of output k ends at tube sample e_k; outputs past
-            // the longest voice's end are masked, so the last block only waits for the final sample
-            needLast = src_position(blk * kCvtCols + (kCvtCols - 1), inc);
+            winBase = src_position(kBase + kLane, inc) & (kYRing - 1) & ~3u;
+            // highest tube sample (of this launch) the block reads: the window of output k ends at tube sample e_k; outputs
+            // past the longest voice's end are masked, so the last block only waits for the final sample
+            needLast = src_position(kBase + blk * kCvtCols + (kCvtCols - 1), inc) - nBase;
             needLast = needLast < nTotal - 1 ? needLast : nTotal - 1;
-            needNext = src_position((blk + 1) * kCvtCols + (kCvtCols - 1), inc);     // (past the end: never "behind")
+            needNext = src_position(kBase + (blk + 1) * kCvtCols + (kCvtCols - 1), inc) - nBase;     // (past the end: never "behind")
             fetch_row(blk);
         };
         if (nBlocks > 0) begin_block();
@@ -617,7 +662,8 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kWave - 1) / kWave;
-    hipLaunchKernelGGL(trm_tube_kernel, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
+    if (a.stream_state) hipLaunchKernelGGL(trm_tube_kernel<true>, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
+    else hipLaunchKernelGGL(trm_tube_kernel<false>, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
     return hipGetLastError();
 }
 
@@ -625,7 +671,7 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 int tube_kernel_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel, kWave * kRoles, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel<false>, kWave * kRoles, 0) != hipSuccess) return -1;
     return n;
 }
 

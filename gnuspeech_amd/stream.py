@@ -20,6 +20,11 @@ class TRMStream:
         if mode != "framework":
             self.set_mode(mode)
 
+    @property
+    def kernel(self):
+        """"wide" (one voice per lane) or "quad" (four lanes per voice): fixed when the stream was created."""
+        return {1: "wide", 2: "quad"}[lib().trm_stream_kernel(self._h)]
+
     def set_mode(self, mode):
         """"framework": Frameworks/Tube's loop (interpolated control periods); "tract": Applications/TRAcT/tube.c's own
         (every frame one control period of held parameters, x10 frication taps, x100 output; tube.c:1096-1190, 1371)."""

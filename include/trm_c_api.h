@@ -306,8 +306,10 @@ int  trm_batch_generate_frames_host(trm_batch *batch, const uint32_t *event_time
  * one-voice stream and pushes the current parameters every control period.
  *
  * All voices of a stream advance together (same number of frames per push).  Output rates above the tube rate
- * (44.1 / 22.05 kHz for the shipped voices) and below it (16 / 8 kHz: the down-sampling branch) both stream; the
- * four-lane kernel form carries it. */
+ * (44.1 / 22.05 kHz for the shipped voices) and below it (16 / 8 kHz: the down-sampling branch) both stream.  Streams of
+ * fewer voices than fill the chip (8192 on MI355X) run the four-lane kernel form, larger ones -- and those whose
+ * converter makes more than four outputs per tube sample (96 kHz output) -- the one-voice-per-lane form; the form is
+ * fixed when the stream is created (trm_stream_kernel). */
 typedef struct trm_stream trm_stream;
 int  trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out);
 void trm_stream_destroy(trm_stream *stream);
@@ -323,6 +325,7 @@ void trm_stream_destroy(trm_stream *stream);
  * Only between utterances (before the first push or after trm_stream_finish); TRM_EINVAL otherwise. */
 enum { TRM_STREAM_MODE_FRAMEWORK = 0, TRM_STREAM_MODE_TRACT = 1 };
 int  trm_stream_set_mode(trm_stream *stream, int mode);
+int  trm_stream_kernel(const trm_stream *stream);          /* TRM_KERNEL_WIDE or TRM_KERNEL_QUAD (below) */
 int  trm_stream_mode(const trm_stream *stream);
 /* Exact number of samples per voice the next push of `nframes` frames (resp. the finish call) returns. */
 size_t trm_stream_samples_for_push(const trm_stream *stream, size_t nframes);

@@ -18,6 +18,19 @@ def g():
     return gnuspeech_amd
 
 
+FORM = {"now": "quad"}
+
+
+@pytest.fixture(autouse=True, params=["quad", "wide"])
+def stream_form(request, monkeypatch):
+    """Every test runs in both streaming kernel forms: four lanes per voice (streams of fewer voices than fill the chip)
+    and one voice per lane (larger ones; here forced onto the tests' few voices by TRM_TUBE_KERNEL, which the library
+    reads when the stream is created)."""
+    monkeypatch.setenv("TRM_TUBE_KERNEL", request.param)
+    FORM["now"] = request.param
+    return request.param
+
+
 def nrms(x, ref, mx):
     if mx == 0.0:                                   # a silent voice: both must be silent
         return 0.0 if not np.any(x) and not np.any(ref) else np.inf
@@ -27,6 +40,7 @@ def nrms(x, ref, mx):
 
 def stream_all(g, pd, fr, chunks):
     s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=fr.shape[0])
+    assert s.kernel == FORM["now"]
     parts, maxes, pos = [], [], 0
     for c in chunks:
         out, m = s.push(fr[:, pos:pos + c])
@@ -41,7 +55,7 @@ def stream_all(g, pd, fr, chunks):
 
 def one_shot(g, pd, frames):
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
-    b.set_kernel("quad")
+    b.set_kernel(FORM["now"])
     pcm, ns, mx = b.synthesize(list(frames))
     return pcm, ns, mx
 
