@@ -550,7 +550,10 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const CT &C, c
         nw.oT[i + 1] += tap[i - 1] * fr;
     }
     {
-        wg_t jp = K.alphaLR * o.oT[3] + (K.alphaLR * o.oB[4] + K.alphaU * o.nB[0]);
+        // (written out as FMAs: left to the compiler, a sum of two products is fused one way or the other depending on
+        // the code around it, and the kernels' two inlined copies of this step -- even / odd samples -- must round alike:
+        // a stream cut at an odd sample count runs every later sample through the other copy)
+        wg_t jp = fma_f((wg_t)K.alphaLR, o.oT[3], fma_f((wg_t)K.alphaLR, o.oB[4], K.alphaU * o.nB[0]));
         nw.oB[3] = (jp - o.oT[3]) * d;
         nw.oT[4] = (jp - o.oB[4]) * d + tap[2] * fr;
         nw.nT[0] = (jp - o.nB[0]) * d;
@@ -585,7 +588,7 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const CT &C, c
         out += rad;
     }
     // throat (:341, TRMFilters.m:72-77)
-    wg_t ty = C.ta0 * E.thr + C.tb1 * L.throatY;
+    wg_t ty = fma_f((wg_t)C.ta0, (wg_t)E.thr, C.tb1 * L.throatY);
     L.throatY = ty;
     out = ty * C.throatGain + out;
     return (float)out;

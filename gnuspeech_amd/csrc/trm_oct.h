@@ -145,7 +145,7 @@ TRM_HD F tube_oct_core(OctState<F> &S, F d, F tg, const OctLane<F> &L, F gin, F 
     S.A0 = S.B.x * d + gin;
     // ---- three-way junction (:801-806); the three alphas sum to 2 (:733-736)
     const F aU = k.y;
-    const F jp = aLR * tX + (aLR * bY + aU * x3);
+    const F jp = fma_f(aLR, tX, fma_f(aLR, bY, aU * x3));
     const F jB = (jp - tX) * d;
     const F jT = (jp - bY) * d + in.y;
     S.jN = (jp - x3) * d;

@@ -186,7 +186,7 @@ TRM_HD F bandpass_eval(F bpA2, F bpB2, F bpG2, F x, F x2, F y1, F y2)
 template <class F>
 TRM_HD F throat_eval(const Const &C, F thr, F y1)
 {
-    return F(C.ta0) * thr + F(C.tb1) * y1;
+    return fma_f(F(C.ta0), thr, F(C.tb1) * y1);      // (the FMA written out: trm_lane.h tube_step)
 }
 
 // One tube sample given the throat output `ty` of that sample and the frication INJECTIONS inA / inB = this part's
@@ -233,7 +233,7 @@ TRM_HD F tube_quad_core(QuadState<F> &S, const Const &C, F gin, F ty, typename P
     // ---- three-way junction (:801-806); the three alphas sum to 2 (:733-736)
     {
         const F aU = kB.y, aLR = fma_f(F(-0.5f), aU, F(1.0f));
-        F jp = aLR * x1 + (aLR * x2 + aU * x3);
+        F jp = fma_f(aLR, x1, fma_f(aLR, x2, aU * x3));
         S.jB = (jp - x1) * d;
         S.jT = (jp - x2) * d + inB.y;
         S.jN = (jp - x3) * d;
