@@ -32,6 +32,7 @@ struct TubeArgs {
     float *tube_out;
     const uint64_t *tube_offset;
     uint32_t nvoices;
+    uint32_t wg_base = 0;         // trm_tube_kernel only: index of the launch's first workgroup within the batch (set by launch_tube)
     uint32_t max_nframes;         // the host sized the noise table (and the tube rows) for this many frames per voice:
                                   // a longer nframes[v] is cut to it (a caller's mistake must not run past them)
     unsigned long long *stamps;   // diagnostic builds only (TRM_STAMP); null in the product

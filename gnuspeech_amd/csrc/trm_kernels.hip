@@ -12,6 +12,7 @@
 //   trm_int16_kernel      output normalisation (TRMTubeModel.m:370-389, 420-484)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -71,7 +72,7 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 //   [0..1] oscillator position (fp64)   [2..25] the FIR's partial sums   [26..57] the 32 travelling waves
 //   [58..68] filter memories            [72..103] the last 32 tube samples (the converter's history)
 template <bool kStream>
-__global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, const TubeArgs A)
+__global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
     __shared__ __attribute__((aligned(16))) float4 sW[2 * kTB * kWave];          // osc -> mix: {wa, wb, ax, ah1}
     __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // mix -> tube: excitation per sample
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
     const int rolePerm[kRoles] = {TRM_ROLE_PERM};
     int role = 0;
     for (int i = 0; i < kRoles; i++) role = waveIdx == i ? rolePerm[i] : role;
-    const uint32_t vRaw = blockIdx.x * kWave + lane;
+    const uint32_t wg = A.wg_base + blockIdx.x;          // (a large batch is launched in slices: launch_tube)
+    const uint32_t vRaw = wg * kWave + lane;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
 
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
         __syncthreads();
         for (int i = threadIdx.x; i < kWave * 32; i += kWave * kRoles) {
             const int q = i >> 5, t = i & 31;
-            const uint32_t vv = blockIdx.x * kWave + q < A.nvoices ? blockIdx.x * kWave + q : A.nvoices - 1;
+            const uint32_t vv = wg * kWave + q < A.nvoices ? wg * kWave + q : A.nvoices - 1;
             const float y = A.stream_state[(size_t)vv * kStreamFloats + 72 + t];
             const uint32_t slot = (nBase - 32u + (uint32_t)t + (kSrcWindow - 1)) & (kYRing - 1);
             sY[q * kYStride + slot] = y;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(kWave *kRoles) void trm_tube_kernel(const Const C, 
             if (lane == 2 * r) myMax = lowHalf;
             if (lane == 2 * r + 1) myMax = highHalf;
         }
-        const uint32_t ov = blockIdx.x * kWave + 32 * cw + (lane & 31);
+        const uint32_t ov = wg * kWave + 32 * cw + (lane & 31);
         const uint32_t nov = __builtin_amdgcn_ds_bpermute(4 * (32 * cw + (lane & 31)), noutLane);
         if (lane < 32 && ov < A.nvoices && C.upsample) {
             A.number_samples[ov] = nov;
@@ -661,9 +663,22 @@ hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hi
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
-    uint32_t grid = (a.nvoices + kWave - 1) / kWave;
-    if (a.stream_state) hipLaunchKernelGGL(trm_tube_kernel<true>, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
-    else hipLaunchKernelGGL(trm_tube_kernel<false>, dim3(grid), dim3(kWave * kRoles), 0, stream, c, a);
+    const uint32_t grid = (a.nvoices + kWave - 1) / kWave;
+    // A grid of more than two rounds of resident workgroups (2 per CU) runs measurably slower per workgroup than its first
+    // two rounds (MI355X, 256 CUs: 1024 workgroups 18.1 ms, 1536: 32.6, 2048: 40.6 -- profiles/wide_slices_r03.txt): the
+    // batch goes out in slices of `slice` workgroups, back to back on the stream.  TRM_WIDE_SLICE overrides (0 = one launch).
+    static const uint32_t slice = [] {
+        const char *e = getenv("TRM_WIDE_SLICE");
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : 1024u;
+    }();
+    TubeArgs s = a;
+    for (uint32_t base = 0; base < grid;) {
+        const uint32_t n = slice == 0 ? grid - base : (grid - base < slice ? grid - base : slice);
+        s.wg_base = base;
+        if (a.stream_state) hipLaunchKernelGGL(trm_tube_kernel<true>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
+        else hipLaunchKernelGGL(trm_tube_kernel<false>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
+        base += n;
+    }
     return hipGetLastError();
 }
 

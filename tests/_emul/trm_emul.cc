@@ -340,3 +340,4 @@ extern "C" int trm_emul_oct_selfcheck(const trm_input_params *p, int iters, unsi
     }
     return bad;
 }
+

@@ -6,7 +6,7 @@ producer that keeps synthesizing from the current parameters a little ahead of t
 streamed through trm_stream_push_device in chunks of 100 ms (25 control frames at 250 Hz) for `seconds` of audio: control
 frames are resident on the device (synthetic config-3 tracks), PCM stays on the device (fp32, one buffer per chunk: a
 server mixes / encodes it there; returning it to the host costs 176 KB per voice-second and bounds N by PCIe, which
-`--host-int16` measures), every chunk is waited for on its own, and a run "holds" N voices if EVERY chunk took less than
+`--host-int16` measures: int16 at a fixed gain into a page-locked host buffer), every chunk is waited for on its own, and a run "holds" N voices if EVERY chunk took less than
 its 100 ms of audio.  Prints the chunk-time distribution per N and the largest N that held.
 
 usage: realtime_voices.py [--seconds 2] [--chunk-frames 25] [--voices N1,N2,...] [--host-int16]"""
@@ -38,9 +38,12 @@ def run(N, seconds, chunk_frames, host_int16):
     per = int(chunk_s * 44100) + 64
     out = torch.empty((N, per), dtype=torch.float32, device=dev)
     mx = torch.empty(N, dtype=torch.float32, device=dev)
-    host = np.empty((N, per), dtype=np.int16) if host_int16 else None
+    host = torch.empty((N, per), dtype=torch.int16, pin_memory=True) if host_int16 else None
     times = []
-    at = 0
+    # warm-up: one chunk of a throw-away utterance (the stream's buffers, the noise table, the kernels' code objects)
+    s.push_device(frames[:, 0:1].contiguous(), out=out, max_out=mx)
+    s.push_device(frames[:, 1:1 + chunk_frames].contiguous(), out=out, max_out=mx)
+    s.finish_device(out=out, max_out=mx)
     s.push_device(frames[:, 0:1].contiguous(), out=out, max_out=mx)        # the utterance's starting point (no samples yet)
     at = 1
     torch.cuda.synchronize()
@@ -52,7 +55,7 @@ def run(N, seconds, chunk_frames, host_int16):
         if host_int16:
             # what a player needs: int16 at a fixed gain (no per-utterance normalisation in a live stream), on the host
             pcm16 = (out[:, :m] * 32767.0).clamp_(-32768, 32767).to(torch.int16)
-            host[:, :m] = pcm16.cpu().numpy()
+            host[:, :m].copy_(pcm16, non_blocking=True)          # page-locked destination: one DMA
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
         at += chunk_frames
