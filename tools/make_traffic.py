@@ -6,13 +6,16 @@ the file bench.py quotes `roofline.traffic` and `roofline.valu_issue` from.  The
 drops the entries of another stamp when it adds one.
 HBM bytes per launch as MI355X_MICROARCH.md prescribes: WRITE_SIZE and FETCH_SIZE collected in SEPARATE passes, both in
 KB, FETCH_SIZE doubled on gfx950 (it counts half of wide coalesced reads).
-usage: make_traffic.py <summary.txt> <voices> <frames> <static|timevarying> <oct|quad|wide> <issue cycles per VALU> [out.json]"""
+`issue cycles per VALU` = `auto`: 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the same pass -- the counter ticks once per four cycles a
+VALU instruction occupies its SIMD (a wave64 instruction on 16 lanes: four; packed, fp64 and transcendental ones longer), so this is
+the kernel's own measured VALU time per instruction (profiles/valu_ceiling_r03.txt).
+usage: make_traffic.py <summary.txt> <voices> <frames> <static|timevarying> <oct|quad|wide> <issue cycles per VALU | auto> [out.json]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
-summary, voices, frames, kind, form, cyc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], float(sys.argv[6])
+summary, voices, frames, kind, form, cyc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
 out = sys.argv[7] if len(sys.argv) > 7 else bench.TRAFFIC_FILE
 vals = {}
 for ln in open(summary):
@@ -20,6 +23,7 @@ for ln in open(summary):
     if m:
         vals[m.group(1)] = float(m.group(2))
 w, f = vals["WRITE_SIZE"], vals["FETCH_SIZE"]
+cyc = 4.0 * vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_INSTS_VALU"] if cyc == "auto" else float(cyc)
 entry = {
     "workload": {"voices_per_gpu": voices, "frames_per_voice": frames, "kind": kind, "kernel_form": form},
     "WRITE_SIZE_KB": w, "FETCH_SIZE_KB": f,
@@ -28,7 +32,8 @@ entry = {
     "SQ_WAIT_ANY_over_WAVE_CYCLES": (vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"]) if vals.get("SQ_WAVE_CYCLES") else None,
     "SQ_LDS_BANK_CONFLICT_over_IDX_ACTIVE": (vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]) if vals.get("SQ_LDS_IDX_ACTIVE") else None,
     "issue_cycles_per_valu": cyc,
-    "issue_cycles_source": "mix-weighted issue cost of the kernel's instruction classes, profiles/valu_ceiling_r03.txt (tools/ubench/valu_ceiling.hip x tools/isa_mix.py)",
+    "SQ_ACTIVE_INST_VALU": vals.get("SQ_ACTIVE_INST_VALU"),
+    "issue_cycles_source": "4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the same PMC pass: the SIMD cycles a VALU instruction of this kernel occupies on average (profiles/valu_ceiling_r03.txt)",
     "source": os.path.relpath(summary, ROOT) + " (separate --pmc passes)",
 }
 stamp = bench.kernel_source_hash()

@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 CSV output (kernel stats + optional PMC passes) into one small text file for profiles/.
 
+A batch of more than 65 536 voices of the one-voice-per-lane kernel goes out as several dispatches per launch (slices of 1024
+workgroups, trm_kernels.hip launch_tube): TRM_SUMMARY_DISPATCHES=N sums the counters of the last N tube-kernel dispatches
+(= one launch) instead of the last one.
 usage: rocprof_summary.py <out.txt> <kernel_trace_dir> [<pmc_dir> ...]"""
 import collections
 import csv
 import glob
+import os
 import sys
 
 
@@ -31,11 +35,15 @@ def main():
                     agg[(int(r["Dispatch_Id"]), r["Counter_Name"])] += float(r["Counter_Value"])
             if not agg:
                 continue
-            last = max(k[0] for k in agg)
-            lines.append("== rocprofv3 --pmc (%s), last trm_tube_kernel dispatch (id %d), summed over XCDs/SEs" % (f, last))
-            for (d, name), v in sorted(agg.items()):
-                if d == last:
-                    lines.append("   %-28s %.6g" % (name, v))
+            nd = int(os.environ.get("TRM_SUMMARY_DISPATCHES", "1"))
+            ids = sorted(set(k[0] for k in agg))[-nd:]
+            lines.append("== rocprofv3 --pmc (%s), last %d trm_tube_kernel dispatch(es) (ids %s) = one launch, summed over XCDs/SEs" % (f, nd, ids))
+            tot = collections.defaultdict(float)
+            for (d, name), v in agg.items():
+                if d in ids:
+                    tot[name] += v
+            for name, v in sorted(tot.items()):
+                lines.append("   %-28s %.6g" % (name, v))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
