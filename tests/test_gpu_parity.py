@@ -355,7 +355,9 @@ def test_synthesizer_facade_and_writers(g, tmp_path):
     assert len(wav) == len(ref_wav) and wav[:46] == ref_wav[:46]                # header bytes identical
     a = np.frombuffer(wav[46:], dtype="<i2").astype(np.int32)
     r = np.frombuffer(ref_wav[46:], dtype="<i2").astype(np.int32)
-    assert np.max(np.abs(a - r)) <= 4 and np.mean(np.abs(a - r)) < 0.6          # int16 LSBs of an fp32 signal path
+    # the fp32 path's error here is 7e-6 of the maximum at its worst sample (RMS 1e-6) and 1e-6 on the maximum itself:
+    # 0.7 LSB after the scale by 32767 x 0.65 -- one LSB where the rounding falls the other way (tools/int16_headroom.py)
+    assert np.max(np.abs(a - r)) <= 1 and np.mean(np.abs(a - r)) < 0.05
     for fmt, ext in ((0, "au"), (1, "aiff"), (2, "wav")):
         syn.shouldSaveToSoundFile = True
         syn.fileType = fmt
@@ -375,7 +377,7 @@ def test_synthesizer_facade_and_writers(g, tmp_path):
         # balance 0.3 in the file path drives the right channel past full scale (scale*2, TRMTubeModel.m:382-383):
         # the reference's int16 cast wraps there, so compare modulo 2^16
         diff = ((body - ref + 32768) % 65536) - 32768
-        assert len(body) == len(ref) and np.max(np.abs(diff)) <= 8
+        assert len(body) == len(ref) and np.max(np.abs(diff)) <= 1      # (x 1.3 in the file path: 0.84 LSB predicted, 1 measured)
 
 
 def cli_argv(tool):
@@ -788,6 +790,44 @@ def test_full_size_properties(g, form):
         o = O.synthesize(op, fr[v].astype(np.float32).astype(np.float64))
         assert nrms(out[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL
 
+
+
+def test_more_than_two_rounds_of_workgroups_go_out_in_slices(g):
+    """The north_star regime (131 072 voices per GPU = 1e6 per node) at a short utterance: 131 072 + 100 voices x 0.1 s run the
+    one-voice-per-lane kernel as three launches (slices of 1024 workgroups, trm_kernels.hip launch_tube).  Size-independent
+    properties across the slice boundaries: exact counts everywhere, finite, the reported maximum is the maximum, identical
+    tracks give identical bits in whichever slice they sit, and voices at the boundaries against the oracle."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    V, n = 131072 + 100, 26
+    base = cases.config3_frames(512, nframes=n).astype(np.float32)
+    fr = np.tile(base, (V // 512 + 1, 1, 1))[:V].copy()
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    st = b.prepare_device(fr)
+    b.synthesize_device(st)
+    torch.cuda.synchronize()
+    assert b.last_kernel == "wide"
+    want = b.samples_for_frames(n)
+    ns = st["number_samples"].cpu().numpy()
+    assert np.all(ns == want)
+    out = st["out"].cpu().numpy().reshape(V, st["out_alloc"] // V)[:, :want]
+    assert np.all(np.isfinite(out))
+    mx = st["max_sample"].cpu().numpy()
+    assert np.array_equal(mx, np.abs(out).max(axis=1))
+    # voice v's track is base[v % 512]: the same bits in the first, second and third slice (65 536 voices each)
+    for v in (0, 5, 511):
+        for w in (v + 65536 - 512, v + 65536, v + 131072 - 512, v + 131072 if v + 131072 < V else v + 65536 + 512):
+            assert np.array_equal(out[v], out[w]), (v, w)
+    op = O.InputParams.from_dict(pd)
+    checked = 0
+    for v in (65535, 65536, 65537, 65600, 131071, 131072, 131073, 131100, V - 1):
+        o = O.synthesize(op, fr[v].astype(np.float64))
+        if o["maximumSampleValue"] == 0.0:             # (a track that starts with silence)
+            assert not np.any(out[v])
+            continue
+        assert nrms(out[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL, v
+        checked += 1
+    assert checked >= 4
 
 
 def test_full_size_ragged_batch_config3(g):
