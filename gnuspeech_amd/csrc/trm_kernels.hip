@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             const uint32_t off = src_position(k, inc) & 3u;
             const float *pc = A.src_rows + (size_t)src_phase(k, inc) * kSrcRowC - off;
             // (the loads land while the wave idles until its next metered pair)
-            for (int q = 0; q < 16; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};
+            for (int q = 0; q < 15; q++) cc[q] = v2f{pc[2 * q], pc[2 * q + 1]};      // (cc[15]: always zeros, unused)
         };
         uint32_t blk = 0, pr = 0;       // next work item: row pair `pr` (0..7) of block `blk`: voices 32*cw + 4*pr .. +3
         uint32_t winBase = 0;           // this lane's aligned window start inside a voice's ring (floats)
@@ -426,8 +426,9 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             v2f b0 = v2f{qb[0].x, qb[0].y} * cc[0], b1 = v2f{qb[0].z, qb[0].w} * cc[1];
             for (int q = 1; q < 8; q++) {
                 a0 = __builtin_elementwise_fma(v2f{qa[q].x, qa[q].y}, cc[2 * q], a0);
-                a1 = __builtin_elementwise_fma(v2f{qa[q].z, qa[q].w}, cc[2 * q + 1], a1);
                 b0 = __builtin_elementwise_fma(v2f{qb[q].x, qb[q].y}, cc[2 * q], b0);
+                if (q == 7) break;      // terms 30, 31: the row is 26 coefficients shifted by at most 3 -- always zeros
+                a1 = __builtin_elementwise_fma(v2f{qa[q].z, qa[q].w}, cc[2 * q + 1], a1);
                 b1 = __builtin_elementwise_fma(v2f{qb[q].z, qb[q].w}, cc[2 * q + 1], b1);
             }
             a0 += a1;

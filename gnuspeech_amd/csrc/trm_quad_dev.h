@@ -71,6 +71,7 @@ __device__ __forceinline__ float cvt_window_dot(const float4 *w, const v2f *cc)
     v2f a1 = v2f{q[0].z, q[0].w} * cc[1];
     for (int i = 1; i < 8; i++) {
         a0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], a0);
+        if (i == 7) break;      // terms 30, 31: the row is 26 coefficients shifted by at most 3 -- always zeros
         a1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], a1);
     }
     a0 += a1;
