@@ -171,9 +171,34 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default=None, choices=["static", "timevarying"],
                     help="overrides --config's: static (config-2 voices) or timevarying (config-3 voices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
+                    help="stream: the metric's second half demonstrated -- --voices N (default 1048576) streamed in 100 ms chunks "
+                         "through trm_stream_push_device for --seconds (default 2) of audio, PCM left on the device; a step = one chunk")
     ap.add_argument("--kernel", default="auto", choices=["auto", "wide", "quad", "oct"],
                     help="kernel form (include/trm_c_api.h); auto = the library's choice by batch size")
     return ap.parse_args(argv)
+
+
+def stream_mode(a, rank, world):
+    """`--mode stream`: concurrent real-time voices measured the way the reference means them (TRAcT's producer loop,
+    Applications/TRAcT/tube.c:1096-1190 + Controller.m:73-100): N voices per GPU streamed in 100 ms chunks, every chunk waited for
+    on its own (tools/realtime_voices.py).  value = output samples/s while streaming; `held` = every chunk beat its audio time."""
+    if world != 1:
+        sys.exit("bench.py --mode stream runs on one GPU (the streams of different GPUs are independent: multiply)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import realtime_voices as rv
+    N = a.voices if a.voices is not None else 1048576
+    seconds = a.seconds if a.seconds != 1.0 else 2.0
+    r = rv.run(N, seconds, 25, False)
+    per_chunk = N * 4410
+    out = {"metric": "audio samples/s (whole node) + concurrent real-time tube voices", "value": per_chunk / (r["median_ms"] * 1e-3), "unit": "samples/s",
+           "n_gpus": 1, "steps": r["chunks"], "warmup": 1, "ms_per_step": r["median_ms"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "realtime_voices_streamed": N, "held_real_time": r["held"], "chunk_ms_audio": r["chunk_ms_audio"], "chunk_ms_max": r["max_ms"],
+           "chunk_ms_p99": r["p99_ms"], "realtime_factor": r["realtime_factor"],
+           "config": {"workload": "%d time-varying voices streamed in 100 ms chunks (25 control frames) for %g s of audio through "
+                                  "trm_stream_push_device; frames and fp32 PCM resident on the device" % (N, seconds), "mode": "stream"}}
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -197,6 +222,9 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world))
     dist = world > 1
     config, voices, workload = resolve_workload(a, world)
+
+    if a.mode == "stream":
+        return stream_mode(a, rank, world)
 
     import numpy as np
     import cases
@@ -313,8 +341,9 @@ def main():
         out["per_gpu_value"] = [samples_per_step_rank / (t * 1e-3) for t in per_rank_ms]
         out["solo_ms_per_step"] = solo_ms                  # rank 0 alone on the same shard, outside the timed region
         out["weak_scaling_efficiency_in_run"] = (solo_ms / (dt / a.steps * 1e3)) if solo_ms else None
-        out["scaling_baseline"] = ("python bench.py --gpus 1 --voices %d --workload %s --seconds %g: the same per-GPU shard on one "
-                                   "GPU (--gpus 1 WITHOUT these flags is configs[1], another workload)" % (voices, workload, a.seconds))
+        out["scaling_baseline"] = ("python bench.py --gpus 1 %s: the same per-GPU shard on one GPU (--gpus 1 WITHOUT that is "
+                                   "configs[1], another workload)" % ("--config %d" % config if (a.voices is None and a.workload is None and a.seconds == 1.0)
+                                                                      else "--voices %d --workload %s --seconds %g" % (voices, workload, a.seconds)))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

@@ -71,6 +71,7 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 // compile-time switch so that the one-shot instance carries none of it.  Per voice kStreamFloats floats of state:
 //   [0..1] oscillator position (fp64)   [2..25] the FIR's partial sums   [26..57] the 32 travelling waves
 //   [58..68] filter memories            [72..103] the last 32 tube samples (the converter's history)
+// stored field-major: field i of voice v at stream_state[i * nvoices + v] (trm_quad.hip's records are voice-major).
 template <bool kStream>
 __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
@@ -110,7 +111,23 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     const bool sFirst = !kStream || (A.stream_flags & 1u), sLast = !kStream || (A.stream_flags & 2u);
     const bool sHold = kStream && (A.stream_flags & 4u);       // TRAcT's loop order: a period runs on the frame that ends it, held
     const uint32_t nBase = kStream ? A.stream_n_base : 0u, kBase = kStream ? A.stream_k_base : 0u;
-    float *const st = kStream ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
+    // this voice's state record, FIELD-major in memory (field i of voice v at [i * nvoices + v]: a wave's 64 lanes touch 64
+    // consecutive floats per field; voice-major records cost 64 cache lines per field and instruction)
+    struct StateRef {
+        float *base;
+        size_t stride;
+        __device__ float &operator[](int i) const { return base[(size_t)i * stride]; }
+    };
+    const StateRef st{kStream ? A.stream_state + v : nullptr, (size_t)A.nvoices};
+    auto st_load_f64 = [&]() {
+        const unsigned long long lo = __builtin_bit_cast(unsigned, st[0]), hi = __builtin_bit_cast(unsigned, st[1]);
+        return __builtin_bit_cast(double, (hi << 32) | lo);
+    };
+    auto st_store_f64 = [&](double x) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+        st[0] = __builtin_bit_cast(float, (unsigned)b);
+        st[1] = __builtin_bit_cast(float, (unsigned)(b >> 32));
+    };
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + (sLast ? 2u * (uint32_t)C.padSize : 0u) : 0;
     // Output rows (64 lanes) a step's kTB tube samples turn into: kTB * 2^16/inc; the convert waves get
     // strictly more than that per step, in row pairs, split between the two waves.
@@ -128,9 +145,9 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         // the last 32 tube samples of the chunks before this one, at their places in the ring (global sample G at slot G + 25)
         __syncthreads();
         for (int i = threadIdx.x; i < kWave * 32; i += kWave * kRoles) {
-            const int q = i >> 5, t = i & 31;
+            const int q = i & (kWave - 1), t = i >> 6;
             const uint32_t vv = wg * kWave + q < A.nvoices ? wg * kWave + q : A.nvoices - 1;
-            const float y = A.stream_state[(size_t)vv * kStreamFloats + 72 + t];
+            const float y = A.stream_state[(size_t)(72 + t) * A.nvoices + vv];
             const uint32_t slot = (nBase - 32u + (uint32_t)t + (kSrcWindow - 1)) & (kYRing - 1);
             sY[q * kYStride + slot] = y;
             if (slot < (uint32_t)kYMirror) sY[q * kYStride + slot + kYRing] = y;
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         auto sine = [&](int i) { return sine_table(i); };
         OscState S;
         ExciteTrack T;
-        S.oscPos = (kStream && !sFirst) ? *reinterpret_cast<const double *>(st) : 0.0;
+        S.oscPos = (kStream && !sFirst) ? st_load_f64() : 0.0;
         // (both frames of a control period are fetched when it starts, once per ~80 samples: carrying the current frame
         // to the next boundary in registers costs a register-to-register copy of it per STEP, the loop's phi nodes)
         auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
                         excite_track_setup(T, C, prev, cur);
                     }
                     OscOut O = osc_sample(S, T, C, (int)j, sine);
-                    if (kStream && n + 1u == ntubeLane && laneValid) *reinterpret_cast<double *>(st) = S.oscPos;   // the chunk's last sample
+                    if (kStream && n + 1u == ntubeLane && laneValid) st_store_f64(S.oscPos);   // the chunk's last sample
                     j++;
                     sW[(buf * kTB + u) * kWave + lane] = make_float4(O.wa, O.wb, O.ax, O.ah1);
                 }
@@ -666,7 +683,7 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
     if (a.nvoices == 0) return hipSuccess;
     const uint32_t grid = (a.nvoices + kWave - 1) / kWave;
     // A grid of more than two rounds of resident workgroups (2 per CU) runs measurably slower per workgroup than its first
-    // two rounds (MI355X, 256 CUs: 1024 workgroups 18.1 ms, 1536: 32.6, 2048: 40.6 -- profiles/wide_slices_r03.txt): the
+    // two rounds (MI355X, 256 CUs: 1024 workgroups 18.1 ms, 1536: 32.6, 2048: 40.6 -- profiles/ab_r03.txt): the
     // batch goes out in slices of `slice` workgroups, back to back on the stream.  TRM_WIDE_SLICE overrides (0 = one launch).
     static const uint32_t slice = [] {
         const char *e = getenv("TRM_WIDE_SLICE");
