@@ -570,7 +570,7 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
             return rc;
         }
     }
-    if ((rc = s->dState.reserve(nvoices * trm::kStreamFloats)) || (rc = s->dLast.reserve(nvoices * 16)) || (rc = s->dFrameOff.reserve(nvoices)) || (rc = s->dOutOff.reserve(nvoices)) ||
+    if ((rc = s->dState.reserve(((nvoices + 63) / 64 * 64) * trm::kStreamFloats)) || (rc = s->dLast.reserve(nvoices * 16)) || (rc = s->dFrameOff.reserve(nvoices)) || (rc = s->dOutOff.reserve(nvoices)) ||
         (rc = s->dNFrames.reserve(nvoices)) || (rc = s->dNSamples.reserve(nvoices)) || (rc = s->dMax.reserve(nvoices))) {
         trm_stream_destroy(s);
         return rc;

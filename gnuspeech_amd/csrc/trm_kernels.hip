@@ -71,7 +71,8 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 // compile-time switch so that the one-shot instance carries none of it.  Per voice kStreamFloats floats of state:
 //   [0..1] oscillator position (fp64)   [2..25] the FIR's partial sums   [26..57] the 32 travelling waves
 //   [58..68] filter memories            [72..103] the last 32 tube samples (the converter's history)
-// stored field-major: field i of voice v at stream_state[i * nvoices + v] (trm_quad.hip's records are voice-major).
+// stored per workgroup as [field][lane]: field i of the workgroup's lane l at stream_state[(wg * kStreamFloats + i) * 64 + l]
+// (trm_quad.hip's records are voice-major); the buffer holds kStreamFloats floats per voice, voices rounded up to 64.
 template <bool kStream>
 __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
@@ -111,14 +112,22 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     const bool sFirst = !kStream || (A.stream_flags & 1u), sLast = !kStream || (A.stream_flags & 2u);
     const bool sHold = kStream && (A.stream_flags & 4u);       // TRAcT's loop order: a period runs on the frame that ends it, held
     const uint32_t nBase = kStream ? A.stream_n_base : 0u, kBase = kStream ? A.stream_k_base : 0u;
-    // this voice's state record, FIELD-major in memory (field i of voice v at [i * nvoices + v]: a wave's 64 lanes touch 64
-    // consecutive floats per field; voice-major records cost 64 cache lines per field and instruction)
+    // this voice's state record: per workgroup a block of [kStreamFloats fields][64 lanes] floats -- a wave's 64 lanes touch
+    // 64 consecutive floats per field (voice-major records cost 64 cache lines per field and instruction) and a field is a
+    // CONSTANT 256 bytes from the one before (one base address per lane: per-field 64-bit strides cost the streaming
+    // instance its registers -- it spilled)
     struct StateRef {
         float *base;
-        size_t stride;
-        __device__ float &operator[](int i) const { return base[(size_t)i * stride]; }
+        // (the opaque copy keeps the address arithmetic inside the rare block that uses it: hoisted out of the step loop
+        // the 28 store addresses of a save were spilled to scratch)
+        __device__ float &operator[](int i) const
+        {
+            float *b = base;
+            asm volatile("" : "+v"(b));
+            return b[i * kWave];
+        }
     };
-    const StateRef st{kStream ? A.stream_state + v : nullptr, (size_t)A.nvoices};
+    const StateRef st{kStream ? A.stream_state + (size_t)wg * kStreamFloats * kWave + lane : nullptr};
     auto st_load_f64 = [&]() {
         const unsigned long long lo = __builtin_bit_cast(unsigned, st[0]), hi = __builtin_bit_cast(unsigned, st[1]);
         return __builtin_bit_cast(double, (hi << 32) | lo);
@@ -146,8 +155,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         __syncthreads();
         for (int i = threadIdx.x; i < kWave * 32; i += kWave * kRoles) {
             const int q = i & (kWave - 1), t = i >> 6;
-            const uint32_t vv = wg * kWave + q < A.nvoices ? wg * kWave + q : A.nvoices - 1;
-            const float y = A.stream_state[(size_t)(72 + t) * A.nvoices + vv];
+            const float y = A.stream_state[((size_t)wg * kStreamFloats + 72 + t) * kWave + q];
             const uint32_t slot = (nBase - 32u + (uint32_t)t + (kSrcWindow - 1)) & (kYRing - 1);
             sY[q * kYStride + slot] = y;
             if (slot < (uint32_t)kYMirror) sY[q * kYStride + slot + kYRing] = y;

@@ -204,3 +204,33 @@ def test_bench_config_flag_names_the_per_gpu_workload():
     assert bench.resolve_workload(bench.parse_args(["--config", "2"]), 1) == (2, 4096, "timevarying")
     assert bench.resolve_workload(bench.parse_args(["--voices", "65536", "--kernel", "wide"]), 1) == (1, 65536, "static")
     assert bench.parse_args([]).steps == 200          # half a second of GPU work: the driver's sampler sees the run
+
+
+def test_no_kernel_spills_or_outgrows_its_register_budget(tmp_path):
+    """The code objects inside the built libtrm_hip.so: no kernel has a private (scratch) segment or spilled registers -- a
+    228-byte spill in the streaming instance of the one-voice-per-lane kernel cost 13 % of its throughput in round 3 (a kernel
+    with scratch pays for it on every dispatch) -- and the pipeline kernels stay within 128 VGPRs: four waves per SIMD is what
+    puts two workgroups on a CU."""
+    import re, shutil, subprocess
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM tools not installed")
+    lib = shutil.copy(os.path.join(ROOT, "gnuspeech_amd", "libtrm_hip.so"), tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert cos, "no gfx950 code object in libtrm_hip.so"
+    kernels = {}
+    for f in cos:
+        notes = subprocess.run([readelf, "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:              # one metadata entry per kernel (its first key)
+            name = re.search(r"\.name:\s+(_Z\S+)", blk)
+            if not name:
+                continue
+            get = lambda key: int(re.search(key + r":\s+(\d+)", blk).group(1))
+            kernels[name.group(1)] = (get(r"\.private_segment_fixed_size"), get(r"\.sgpr_spill_count"), get(r"\.vgpr_spill_count"), get(r"\.vgpr_count"))
+    tube = [k for k in kernels if "trm_tube_kernel" in k]
+    assert len(tube) == 6, sorted(kernels)           # wide x2 (one-shot, stream), quad x3, oct
+    for k, (scratch, sspill, vspill, vgprs) in kernels.items():
+        assert scratch == 0 and sspill == 0 and vspill == 0, (k, scratch, sspill, vspill)
+    for k in tube:
+        assert kernels[k][3] <= 128, (k, kernels[k][3])

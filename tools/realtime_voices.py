@@ -35,7 +35,7 @@ def run(N, seconds, chunk_frames, host_int16):
         frames = frames.repeat((N + frames.shape[0] - 1) // frames.shape[0], 1, 1)[:N].contiguous()
     s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=N)
     chunk_s = chunk_frames / 250.0
-    per = int(chunk_s * 44100) + 64
+    per = (int(chunk_s * 44100) + 64 + 31) & ~31          # rows on 128-byte boundaries: the kernel stores 128-byte pieces of PCM
     out = torch.empty((N, per), dtype=torch.float32, device=dev)
     mx = torch.empty(N, dtype=torch.float32, device=dev)
     host = torch.empty((N, per), dtype=torch.int16, pin_memory=True) if host_int16 else None
