@@ -449,13 +449,15 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             // 32-term dot products as packed FMAs: (even, odd) partial sums, two chains per row
             v2f a0 = v2f{qa[0].x, qa[0].y} * cc[0], a1 = v2f{qa[0].z, qa[0].w} * cc[1];
             v2f b0 = v2f{qb[0].x, qb[0].y} * cc[0], b1 = v2f{qb[0].z, qb[0].w} * cc[1];
-            for (int q = 1; q < 8; q++) {
+            for (int q = 1; q < 7; q++) {
                 a0 = __builtin_elementwise_fma(v2f{qa[q].x, qa[q].y}, cc[2 * q], a0);
-                b0 = __builtin_elementwise_fma(v2f{qb[q].x, qb[q].y}, cc[2 * q], b0);
-                if (q == 7) break;      // terms 30, 31: the row is 26 coefficients shifted by at most 3 -- always zeros
                 a1 = __builtin_elementwise_fma(v2f{qa[q].z, qa[q].w}, cc[2 * q + 1], a1);
+                b0 = __builtin_elementwise_fma(v2f{qb[q].x, qb[q].y}, cc[2 * q], b0);
                 b1 = __builtin_elementwise_fma(v2f{qb[q].z, qb[q].w}, cc[2 * q + 1], b1);
             }
+            // (terms 30, 31 are always zeros: the row is 26 coefficients shifted by at most 3)
+            a0 = __builtin_elementwise_fma(v2f{qa[7].x, qa[7].y}, cc[14], a0);
+            b0 = __builtin_elementwise_fma(v2f{qb[7].x, qb[7].y}, cc[14], b0);
             a0 += a1;
             b0 += b1;
             const float ya = a0.x + a0.y, yb = b0.x + b0.y;

@@ -69,11 +69,11 @@ __device__ __forceinline__ float cvt_window_dot(const float4 *w, const v2f *cc)
     for (int i = 0; i < 8; i++) q[i] = w[i];
     v2f a0 = v2f{q[0].x, q[0].y} * cc[0];
     v2f a1 = v2f{q[0].z, q[0].w} * cc[1];
-    for (int i = 1; i < 8; i++) {
+    for (int i = 1; i < 7; i++) {
         a0 = __builtin_elementwise_fma(v2f{q[i].x, q[i].y}, cc[2 * i], a0);
-        if (i == 7) break;      // terms 30, 31: the row is 26 coefficients shifted by at most 3 -- always zeros
         a1 = __builtin_elementwise_fma(v2f{q[i].z, q[i].w}, cc[2 * i + 1], a1);
     }
+    a0 = __builtin_elementwise_fma(v2f{q[7].x, q[7].y}, cc[14], a0);      // (terms 30, 31 are always zeros: 26 coefficients shifted by at most 3)
     a0 += a1;
     return a0.x + a0.y;
 }

@@ -2,7 +2,10 @@
 """Randomized check of the streaming entry (trm_stream_*): random parameters (both converter branches), random cuts.
 A chunked stream must equal the single-push stream bit for bit, and the one-shot batch result to rounding (same count,
 except where the reference's one-shot converter ends on its extra lap).
-usage: fuzz_stream.py first_seed last_seed"""
+TRM_TUBE_KERNEL=quad|wide picks the streaming kernel form; `tract` as third argument streams in TRAcT's loop order
+(TRM_STREAM_MODE_TRACT) and compares with the oracle in that order (trm_oracle_synthesize_tract) at 1e-5 instead of with the
+one-shot batch.
+usage: fuzz_stream.py first_seed last_seed [tract]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +14,15 @@ import cases
 import gnuspeech_amd as g
 from gnuspeech_amd import shard
 
+def d_rate(ip):
+    return shard.derive(ip)["sampleRate"]
+
+
 first, last = int(sys.argv[1]), int(sys.argv[2])
+tract = len(sys.argv) > 3 and sys.argv[3] == "tract"
+mode = "tract" if tract else "framework"
+if tract:
+    import oracle_lib as O
 bad = 0
 rows = cases.load_gnuspeech_rows()
 for seed in range(first, last):
@@ -25,7 +36,7 @@ for seed in range(first, last):
     fr[:, :, 0] += rng.uniform(-4, 4, (V, 1)).astype(np.float32)
     ip = g.TRMInputParameters.from_dict(pd)
     try:
-        s1 = g.TRMStream(ip, nvoices=V)
+        s1 = g.TRMStream(ip, nvoices=V, mode=mode)
     except g.TrmError as e:
         continue                                            # (rate ratio above 4: streams refuse)
     def run(stream, cuts):
@@ -39,9 +50,21 @@ for seed in range(first, last):
     left = n
     while left > 0:
         c = int(min(left, rng.integers(1, max(2, n // 3 + 1)))); cuts.append(c); left -= c
-    got = run(g.TRMStream(ip, nvoices=V), cuts)
+    got = run(g.TRMStream(ip, nvoices=V, mode=mode), cuts)
     if got.shape != whole.shape or not np.array_equal(got.view(np.uint32), whole.view(np.uint32)):
         print("seed %d: chunked != whole (rate %.0f, length %.1f, V %d, n %d, cuts %s)" % (seed, pd["outputRate"], pd["length"], V, n, cuts)); bad += 1
+        continue
+    if tract:
+        op = O.InputParams.from_dict(pd)
+        for v in range(V):
+            o = O.synthesize(op, np.concatenate([fr[v][:1], fr[v]]).astype(np.float64), tract=True)
+            if whole.shape[1] != o["numberSamples"]:
+                print("seed %d voice %d: count %d vs oracle %d" % (seed, v, whole.shape[1], o["numberSamples"])); bad += 1; continue
+            if o["maximumSampleValue"] == 0: continue
+            e = (whole[v].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
+            r = float(np.sqrt(np.mean(e * e)))
+            if not r <= 1e-5 and not cases.bandpass_unstable(fr[v], d_rate(ip)):
+                print("seed %d voice %d: tract-order stream vs oracle rms %.3e (rate %.0f, length %.1f)" % (seed, v, r, pd["outputRate"], pd["length"])); bad += 1
         continue
     b = g.TRMBatch(ip); b.set_kernel("quad")
     pcm, ns, mx = b.synthesize(list(fr))
