@@ -271,3 +271,68 @@ def test_device_buffer_entries_equal_the_host_entries(g, rate, mode):
     assert pos == want.shape[1]
     assert np.array_equal(big[:, :pos].cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert float(big[:, pos:].abs().max()) == 0.0                                      # nothing written past the samples
+
+
+def test_large_wide_stream_across_launch_slices(g, stream_form):
+    """A stream of more voices than one launch slice of the one-voice-per-lane kernel holds (65 536): its per-workgroup state
+    blocks, the sliced launches and the device-buffer entries together -- identical tracks give identical bits in whichever
+    slice they sit, chunked == single push bit for bit, and voices at the slice boundary agree with the oracle."""
+    import torch
+    import oracle_lib as O
+    if stream_form != "wide":
+        pytest.skip("the one-voice-per-lane form's launch slices")
+    pd = cases.monet_default_params(44100.0)
+    V, n = 65536 + 200, 13
+    base = cases.config3_frames(256, nframes=n, seed=20250512).astype(np.float32)
+    fr = np.tile(base, (V // 256 + 1, 1, 1))[:V].copy()
+    dev = torch.device("cuda", 0)
+    frd = torch.from_numpy(fr).to(dev)
+
+    def run(cuts):
+        s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=V)
+        assert s.kernel == "wide"
+        parts, at = [], 0
+        for c in cuts:
+            o, m = s.push_device(frd[:, at:at + c].contiguous())
+            parts.append(o.clone()); at += c
+        o, m = s.finish_device(device=dev)
+        parts.append(o.clone())
+        torch.cuda.synchronize()
+        return torch.cat(parts, dim=1).cpu().numpy()
+    whole = run([n])
+    cut = run([1, 5, 7])
+    assert np.array_equal(whole.view(np.uint32), cut.view(np.uint32))
+    for v in (0, 3, 199):                               # voice v and v + 65 536 run the same track in different slices
+        assert np.array_equal(whole[v], whole[v + 65536]), v
+    op = O.InputParams.from_dict(pd)
+    checked = 0
+    for v in (65535, 65536, 65537, 65600, V - 1):
+        o = O.synthesize(op, fr[v].astype(np.float64))
+        assert whole.shape[1] == o["numberSamples"]
+        if o["maximumSampleValue"] == 0.0:
+            continue
+        assert nrms(whole[v], o["samples"], o["maximumSampleValue"]) <= 1e-5, v
+        checked += 1
+    assert checked >= 2
+
+
+def test_stream_corner_calls(g):
+    """finish without a push, a first push of one frame (no samples yet), pushes after finish, device entries with nothing to return."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    fr = cases.config3_frames(3, nframes=9, seed=7).astype(np.float32)
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=3)
+    o, m = s.finish()
+    assert o.shape == (3, 0)
+    o, m = s.push(fr[:, :1])
+    assert o.shape == (3, 0) and not np.any(m)
+    dev = torch.device("cuda", 0)
+    o2, n2 = s.push_device(torch.from_numpy(fr[:, 1:4]).to(dev).contiguous())
+    assert n2 == o2.shape[1] > 0
+    tail, _ = s.finish()
+    # the same utterance again on the same stream object, host entries only: the same bits
+    a = s.push(fr[:, :1])[0]; b = s.push(fr[:, 1:4])[0]; c = s.finish()[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(b, o2.cpu().numpy()) and np.array_equal(c, tail)
+    o3, n3 = s.finish_device(device=dev)
+    assert n3 == 0
