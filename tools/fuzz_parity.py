@@ -10,7 +10,7 @@ import gnuspeech_amd as g
 first, last = int(sys.argv[1]), int(sys.argv[2])
 maxframes = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 broad = len(sys.argv) > 4 and sys.argv[4] == "broad"        # wider (still legal) parameter and track ranges
-bad = 0; unstable = 0; floor = 0; worst = 0.0; worstBy = {}
+bad = 0; unstable = 0; floor = 0; worst = 0.0; worstBy = {}; allr = []
 for seed in range(first, last):
     rng = np.random.default_rng(5000 + seed)
     pd = cases.monet_default_params(float(rng.choice([22050.0, 44100.0, 16000.0, 8000.0, 11025.0, 48000.0, 32000.0, 12000.0, 96000.0])))
@@ -62,9 +62,15 @@ for seed in range(first, last):
             r, a = cases.parity_error(pcm[v], o["samples"], o["maximumSampleValue"])
             if not r <= 1e-5 and a <= cases.ABS_FLOOR: floor += 1; continue      # a nearly silent voice, matched absolutely
             worst = max(worst, r)
+            allr.append((r, seed, form, v, len(voices[v]), int(ns[v]), pd["outputRate"]))
             if r > worstBy.get(form, (0.0, -1, -1))[0]: worstBy[form] = (r, seed, v)
             if not r <= 1e-5:
                 print("seed %d %s voice %d (%d frames, length %.1f, rate %.0f/%.0f): rms %.3e" % (seed, form, v, len(voices[v]), pd["length"], pd["outputRate"], pd["controlRate"], r)); bad += 1
 print("done: seeds %d..%d, %d findings; worst normalised RMS %.3e; %d voice-runs outside the band-pass's domain (BW >= SR/2), %d nearly silent ones matched on the absolute floor %.0e"
       % (first, last, bad, worst, unstable, floor, cases.ABS_FLOOR))
 print("worst per form: " + "; ".join("%s %.3e (seed %d voice %d)" % ((f,) + worstBy[f]) for f in sorted(worstBy)))
+allr.sort(reverse=True)
+print("the ten largest: " + "; ".join("%.2e (seed %d %s voice %d: %d frames, %d samples, %.0f Hz)" % t for t in allr[:10]))
+if allr:
+    rs = np.array([t[0] for t in allr])
+    print("distribution over %d voice-runs: median %.2e, 99th percentile %.2e, above 5e-6: %d" % (len(rs), np.median(rs), np.percentile(rs, 99), int((rs > 5e-6).sum())))
