@@ -204,6 +204,7 @@ def test_bench_config_flag_names_the_per_gpu_workload():
     assert bench.resolve_workload(bench.parse_args(["--config", "2"]), 1) == (2, 4096, "timevarying")
     assert bench.resolve_workload(bench.parse_args(["--voices", "65536", "--kernel", "wide"]), 1) == (1, 65536, "static")
     assert bench.parse_args([]).steps == 200          # half a second of GPU work: the driver's sampler sees the run
+    assert bench.parse_args([]).mode == "batch" and bench.parse_args(["--mode", "stream", "--voices", "2097152"]).mode == "stream"
 
 
 def test_no_kernel_spills_or_outgrows_its_register_budget(tmp_path):
