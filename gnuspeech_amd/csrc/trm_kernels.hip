@@ -24,9 +24,33 @@
 #ifndef TRM_EXPERIMENTS
 #undef TRM_ABL
 #undef TRM_ROLE_PERM
+#undef TRM_PRIO_OSC
+#undef TRM_PRIO_MIX
+#undef TRM_PRIO_COEF
+#undef TRM_PRIO_TUBE
+#undef TRM_PRIO_CVT
 #endif
 #ifndef TRM_ABL
 #define TRM_ABL 0    // diagnostic ablations of the convert stage; 0 in the product
+#endif
+// Issue priority per role (s_setprio, 0..3).  The kernel is VALU-throughput bound (91 % of the SIMDs' time is VALU issue with all
+// roles at priority 0); what is left is waves waiting at the step barrier for the role that got its issue slots last.  Serving
+// the roles in the order convert > tube > oscillator > {coefficients, mix} took the saturating batch from 17.2 to 15.7 ms
+// (profiles/ab_r03.txt: 25 orders timed; the order is strict -- coefficient or mix waves above the oscillator cost 20-40 %).
+#ifndef TRM_PRIO_CVT
+#define TRM_PRIO_CVT 3
+#endif
+#ifndef TRM_PRIO_TUBE
+#define TRM_PRIO_TUBE 2
+#endif
+#ifndef TRM_PRIO_OSC
+#define TRM_PRIO_OSC 1
+#endif
+#ifndef TRM_PRIO_MIX
+#define TRM_PRIO_MIX 0
+#endif
+#ifndef TRM_PRIO_COEF
+#define TRM_PRIO_COEF 0
 #endif
 
 namespace trm {
@@ -90,7 +114,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     // wave -> role.  A workgroup's waves are dealt to the CU's 4 SIMDs in turn, so waves w and w+4 share
     // one SIMD's issue slots: TRM_ROLE_PERM lists the role of each wave (diagnostic builds may override it).
 #ifndef TRM_ROLE_PERM
-#define TRM_ROLE_PERM 5, 6, 0, 4, 2, 3, 1   /* convert0 convert1 osc tube | coef0 coef1 mix */
+#define TRM_ROLE_PERM 5, 6, 4, 0, 2, 3, 1   /* convert0 convert1 tube osc | coef0 coef1 mix (140 of the 1260 orders timed, profiles/ab_r03.txt) */
 #endif
     const int waveIdx = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int rolePerm[kRoles] = {TRM_ROLE_PERM};
@@ -165,6 +189,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
 
     if (role == 0) {
         // ------------------------------------------------------------ osc: tracks + oscillator, block i at step i
+        __builtin_amdgcn_s_setprio(TRM_PRIO_OSC);
         auto sine = [&](int i) { return sine_table(i); };
         OscState S;
         ExciteTrack T;
@@ -201,6 +226,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         STAMP_STORE(role)
     } else if (role == 1) {
         // ------------------------------------------------------------ mix: FIR + noise mixing, block i-1 at step i
+        __builtin_amdgcn_s_setprio(TRM_PRIO_MIX);
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
             dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
         };
@@ -248,6 +274,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     } else if (role == 2 || role == 3) {
         // ------------------------------------------------------------ coef (this wave: samples of parity u), block i-1 at step i
         const int u = role - 2;
+        __builtin_amdgcn_s_setprio(TRM_PRIO_COEF);
         CoefTrack T;
         auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
         // position of this wave's next sample in its control period; the first sample starts period 1
@@ -285,6 +312,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-2 at step i
         // two wave sets: sample 2i steps wA -> wB, sample 2i+1 steps wB -> wA (kTB == 2: no state copies)
+        __builtin_amdgcn_s_setprio(TRM_PRIO_TUBE);
         Waves wA, wB;
         TubeFilters F;
         waves_reset(wA);
@@ -368,6 +396,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     } else {
         // ------------------------------------------------------------ convert (lane = output time)
         const int cw = role - 5;                    // this wave converts voices 32*cw .. 32*cw+31
+        __builtin_amdgcn_s_setprio(TRM_PRIO_CVT);
         // outputs of this launch per voice: the utterance's (TRMSampleRateConverter.m:160-173); a chunk's: global indices
         // kBase <= k < stream_k_end, the same for every voice
         uint32_t noutLane = 0;

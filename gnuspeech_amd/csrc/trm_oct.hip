@@ -26,6 +26,11 @@
 #ifndef TRM_EXPERIMENTS
 #undef TRM_OCT_ROLE_PERM
 #undef TRM_OCT_TUBE_PRIO
+#undef TRM_OCT_PRIO_OSC
+#undef TRM_OCT_PRIO_MIX
+#undef TRM_OCT_PRIO_COEF
+#undef TRM_OCT_PRIO_COEF2
+#undef TRM_OCT_PRIO_CVT
 #undef TRM_ABL_SKIP
 #undef TRM_ISA_ROLE
 #endif
@@ -259,6 +264,10 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
     }
 #endif
     if (role == 0) {
+#ifndef TRM_OCT_PRIO_OSC
+#define TRM_OCT_PRIO_OSC 1
+#endif
+        __builtin_amdgcn_s_setprio(TRM_OCT_PRIO_OSC);
         // ------------------------------------------------------------ osc: block i at step i, lane = (voice, slot)
         auto sine = [&](int i) { return sine_table(i); };
         // The control-period set-up (four fp64 exponentials) runs ONCE per period and wave: the lanes of a voice enter a
@@ -351,6 +360,9 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         }
         STAMP_STORE(role)
     } else if (role == 1) {
+#ifdef TRM_OCT_PRIO_MIX
+        __builtin_amdgcn_s_setprio(TRM_OCT_PRIO_MIX);
+#endif
         // ------------------------------------------------------------ mix: block i-1 at step i, lane = (voice, slot)
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
             dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
@@ -422,6 +434,12 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         STAMP_STORE(role)
         dma_wait_all();
     } else if (role == 2 || role == 3) {
+#ifdef TRM_OCT_PRIO_COEF
+        if (role == 2) __builtin_amdgcn_s_setprio(TRM_OCT_PRIO_COEF);
+#endif
+#ifdef TRM_OCT_PRIO_COEF2
+        if (role == 3) __builtin_amdgcn_s_setprio(TRM_OCT_PRIO_COEF2);
+#endif
         // ------------------------------------------------------------ coef: block i-2 at step i, lane = (voice, slot).
         // Role 2 turns radii and velum into the junctions' transmission factors (stateless in time), role 3 the frication
         // tracks into taps and band-pass coefficients, runs the band-pass over the mix wave's noise signal (written during
@@ -582,6 +600,11 @@ __global__ __launch_bounds__(kWave *kORoles, 4) void trm_tube_kernel_o(const Con
         }
         STAMP_STORE(role)
     } else {
+        // (tube 3 > convert 2 > oscillator 1 > the rest: 2.41 -> 2.375 ms at the bench batch, profiles/ab_r03.txt)
+#ifndef TRM_OCT_PRIO_CVT
+#define TRM_OCT_PRIO_CVT 2
+#endif
+        __builtin_amdgcn_s_setprio(TRM_OCT_PRIO_CVT);
         // ------------------------------------------------------------ convert (lane = output time), 8 voices
         uint32_t noutLane = 0;
         if (nfr > 0) {

@@ -30,6 +30,12 @@
 #undef TRM_ABL_CVT
 #undef TRM_ABL_SKIP
 #undef TRM_QROLE_PERM
+#undef TRM_QPRIO_TUBE
+#undef TRM_QPRIO_OSC
+#undef TRM_QPRIO_MIX
+#undef TRM_QPRIO_COEF
+#undef TRM_QPRIO_COEF2
+#undef TRM_QPRIO_CVT
 #undef TRM_THROAT_IN_OSC
 #endif
 #ifndef TRM_ABL_CVT
@@ -256,6 +262,9 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     }
 #endif
     if (role == 0) {
+#ifdef TRM_QPRIO_OSC
+        __builtin_amdgcn_s_setprio(TRM_QPRIO_OSC);
+#endif
         // ------------------------------------------------------------ osc: block i at step i, lane = (voice, slot)
         auto sine = [&](int i) { return sine_table(i); };
         OscSlotTrack T;
@@ -353,6 +362,9 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             }
         }
     } else if (role == 1) {
+#ifdef TRM_QPRIO_MIX
+        __builtin_amdgcn_s_setprio(TRM_QPRIO_MIX);
+#endif
         // ------------------------------------------------------------ mix: block i-1 at step i, lane = (voice, slot)
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
             dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
@@ -440,6 +452,12 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         STAMP_STORE(role)
         dma_wait_all();
     } else if (role == 2 || role == 3) {
+#ifdef TRM_QPRIO_COEF
+        if (role == 2) __builtin_amdgcn_s_setprio(TRM_QPRIO_COEF);
+#endif
+#ifdef TRM_QPRIO_COEF2
+        if (role == 3) __builtin_amdgcn_s_setprio(TRM_QPRIO_COEF2);
+#endif
         // ------------------------------------------------------------ coef: block i-2 at step i, lane = (voice, slot).
         // Two waves share the stage by FUNCTION: role 2 turns radii and velum into the junctions' transmission factors
         // (stateless in time), role 3 turns the frication tracks into taps and band-pass coefficients, runs the band-pass
@@ -530,7 +548,10 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         // ------------------------------------------------------------ tube: block i-4 at step i, lane = (voice, part)
         // the only serial role: where it shares a SIMD (two workgroups on a CU) its instructions go first (8192 voices:
         // 4.54 -> 4.33 ms, profiles/role_perm_r02.txt)
-        __builtin_amdgcn_s_setprio(3);
+#ifndef TRM_QPRIO_TUBE
+#define TRM_QPRIO_TUBE 3
+#endif
+        __builtin_amdgcn_s_setprio(TRM_QPRIO_TUBE);
         QuadState<float> S;
         quad_reset(S);
         float *const stTube = streaming ? st + 104 + 20 * part : nullptr;
@@ -622,6 +643,9 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         }
         STAMP_STORE(role)
     } else {
+#ifdef TRM_QPRIO_CVT
+        __builtin_amdgcn_s_setprio(TRM_QPRIO_CVT);
+#endif
         // ------------------------------------------------------------ convert (lane = output time), 16 voices
         uint32_t noutLane = 0;
         if (streaming) {

@@ -9,8 +9,14 @@ NAME=$1; shift
 SRC=${SRC:-trm_quad}
 [ -n "$WIDE" ] && SRC=trm_kernels
 FLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize"
-SCHED=${SCHED:-iterative-ilp}      # the scheduler strategy of the multi-lane kernels (Makefile: QUADFLAGS); SCHED=none = the compiler's default
-[ "$SRC" != trm_kernels ] && [ "$SCHED" != none ] && FLAGS="$FLAGS -mllvm -amdgpu-sched-strategy=$SCHED"
+# per-file scheduler flags as in the Makefile (QUADFLAGS / OCTFLAGS / WIDEFLAGS); SCHED=<strategy> overrides the strategy, SCHED=none = the
+# compiler's default scheduling
+case $SRC in
+  trm_kernels) DEF="-mllvm -amdgpu-sched-strategy=${SCHED:-max-ilp} -mllvm -enable-post-misched=false" ;;
+  trm_quad)    DEF="-mllvm -amdgpu-sched-strategy=${SCHED:-iterative-ilp} -mllvm -enable-post-misched=false" ;;
+  *)           DEF="-mllvm -amdgpu-sched-strategy=${SCHED:-iterative-ilp}" ;;
+esac
+[ "$SCHED" != none ] && FLAGS="$FLAGS $DEF"
 mkdir -p build/var_$NAME
 hipcc --offload-arch=gfx950 $FLAGS "$@" -c $SRC.hip -o build/var_$NAME/$SRC.o
 OBJS=""
