@@ -29,14 +29,19 @@
 #undef TRM_PRIO_COEF
 #undef TRM_PRIO_TUBE
 #undef TRM_PRIO_CVT
+#undef TRM_PRIO_CVT_S
+#undef TRM_PRIO_TUBE_S
+#undef TRM_PRIO_OSC_S
 #endif
 #ifndef TRM_ABL
 #define TRM_ABL 0    // diagnostic ablations of the convert stage; 0 in the product
 #endif
 // Issue priority per role (s_setprio, 0..3).  The kernel is VALU-throughput bound (91 % of the SIMDs' time is VALU issue with all
 // roles at priority 0); what is left is waves waiting at the step barrier for the role that got its issue slots last.  Serving
-// the roles in the order convert > tube > oscillator > {coefficients, mix} took the saturating batch from 17.2 to 15.7 ms
+// the roles in the order convert > tube > oscillator > {coefficients, mix} took the saturating batch from 17.2 to 15.5 ms
 // (profiles/ab_r03.txt: 25 orders timed; the order is strict -- coefficient or mix waves above the oscillator cost 20-40 %).
+// The streaming instance wants tube == oscillator: with the one-shot order a 100 ms chunk of 1 M voices takes 39 ms, with
+// convert 3 > tube 1 = oscillator 1 it takes 27.7 ms (30.8 without priorities) -- TRM_PRIO_*_S, same file.
 #ifndef TRM_PRIO_CVT
 #define TRM_PRIO_CVT 3
 #endif
@@ -45,6 +50,15 @@
 #endif
 #ifndef TRM_PRIO_OSC
 #define TRM_PRIO_OSC 1
+#endif
+#ifndef TRM_PRIO_CVT_S
+#define TRM_PRIO_CVT_S 3
+#endif
+#ifndef TRM_PRIO_TUBE_S
+#define TRM_PRIO_TUBE_S 1
+#endif
+#ifndef TRM_PRIO_OSC_S
+#define TRM_PRIO_OSC_S 1
 #endif
 #ifndef TRM_PRIO_MIX
 #define TRM_PRIO_MIX 0
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
 
     if (role == 0) {
         // ------------------------------------------------------------ osc: tracks + oscillator, block i at step i
-        __builtin_amdgcn_s_setprio(TRM_PRIO_OSC);
+        __builtin_amdgcn_s_setprio(kStream ? TRM_PRIO_OSC_S : TRM_PRIO_OSC);
         auto sine = [&](int i) { return sine_table(i); };
         OscState S;
         ExciteTrack T;
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     } else if (role == 4) {
         // ------------------------------------------------------------ tube: block i-2 at step i
         // two wave sets: sample 2i steps wA -> wB, sample 2i+1 steps wB -> wA (kTB == 2: no state copies)
-        __builtin_amdgcn_s_setprio(TRM_PRIO_TUBE);
+        __builtin_amdgcn_s_setprio(kStream ? TRM_PRIO_TUBE_S : TRM_PRIO_TUBE);
         Waves wA, wB;
         TubeFilters F;
         waves_reset(wA);
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     } else {
         // ------------------------------------------------------------ convert (lane = output time)
         const int cw = role - 5;                    // this wave converts voices 32*cw .. 32*cw+31
-        __builtin_amdgcn_s_setprio(TRM_PRIO_CVT);
+        __builtin_amdgcn_s_setprio(kStream ? TRM_PRIO_CVT_S : TRM_PRIO_CVT);
         // outputs of this launch per voice: the utterance's (TRMSampleRateConverter.m:160-173); a chunk's: global indices
         // kBase <= k < stream_k_end, the same for every voice
         uint32_t noutLane = 0;
