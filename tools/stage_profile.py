@@ -44,14 +44,14 @@ for r in range(NR):
     w, q = np.median(s[:, r, 0]) / ntube, np.median(s[:, r, 1]) / ntube
     nl, ex, mxs = np.median(s[:, r, 5]), np.median(s[:, r, 6]), np.median(s[:, r, 7])
     print("  %-8s work %7.0f  barrier-wait %7.0f  total %7.0f   long steps %5.0f (excess %6.0f cycles each), longest %6.0f" % (names[r], w, q, w + q, nl, ex / max(nl, 1), mxs))
-if quad:
-    # HW_ID (gfx9 layout): wave slot [3:0], SIMD [5:4], CU [11:8]: which roles share a SIMD
-    hw = buf.reshape(nwg, NR, 8)[:, :, 2].astype(np.int64)
-    simd = (hw >> 4) & 3
-    pat = {}
-    for row in simd:
-        pat[tuple(row)] = pat.get(tuple(row), 0) + 1
-    print("  SIMD of (%s): %s" % (", ".join(names), "; ".join("%s x%d" % ("".join(map(str, k)), n) for k, n in sorted(pat.items(), key=lambda kv: -kv[1])[:8])))
+# HW_ID (gfx9 layout): wave slot [3:0], SIMD [5:4], CU [11:8]: which roles share a SIMD
+# (one-voice-per-lane kernel: the convert waves' slots hold their sub-phase times instead, so only the first five roles are listed)
+hw = buf.reshape(nwg, NR, 8)[:, :(NR if quad else 5), 2].astype(np.int64)
+simd = (hw >> 4) & 3
+pat = {}
+for row in simd:
+    pat[tuple(row)] = pat.get(tuple(row), 0) + 1
+print("  SIMD of (%s): %s" % (", ".join(names[:simd.shape[1]]), "; ".join("%s x%d" % ("".join(map(str, k)), n) for k, n in sorted(pat.items(), key=lambda kv: -kv[1])[:8])))
 if quad:
     # which workgroups shared a CU (HW_ID: CU [11:8], SH [12], SE [15:13]; the XCD is not in HW_ID, so up to 8 CUs
     # alias one key: read the PATTERNS of the tube wave's SIMD among the workgroups of a key, not the counts)
