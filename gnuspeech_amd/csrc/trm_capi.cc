@@ -575,6 +575,13 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
         trm_stream_destroy(s);
         return rc;
     }
+    // The noise sequence of the first 16 s (24 s with ensure_noise's head-room) is fetched now, not chunk by chunk: extending it is
+    // a serial kernel, a synchronisation and a re-upload, i.e. a chunk that takes 2 ms longer than its neighbours (the sequence is
+    // generated once per process, later streams only upload it).
+    if ((rc = ensure_noise(b, 16u * (uint32_t)b->d.sampleRate, b->stream))) {
+        trm_stream_destroy(s);
+        return rc;
+    }
     *out = s;
     return TRM_OK;
 }
