@@ -216,21 +216,19 @@ TRM_HD float amplitude_f(float db)
 // (TRMWavetable.m:79-96 rise/closed, :117-156 fall rewritten from the amplitude).
 // The three regions without a compare or a select: with x and xf clamped to [0, 1] the rise polynomial is exactly 1 from
 // the end of the rise on and the fall exactly 1 before its start, so the entry is their PRODUCT (one factor is always
-// exactly 1: the product is the other one, bit for bit); the closed phase is a factor that is exactly 1 below newDiv2
-// and 0 from there on (integers in floats).  fi = the entry's index as a float.
+// exactly 1: the product is the other one, bit for bit); the closed phase is the fall's clamp at 1.  fi = the entry's index as a float.
 TRM_HD float pulse_table_f(float fi, float fDiv1, float invDiv1, float fNewDiv2, float invFall)
 {
+    (void)fDiv1;
     const float x = sat_f(fi * invDiv1);
     const float rise = x * x * fma_f(-2.0f, x, 3.0f);
-    const float xf = sat_f((fi - fDiv1) * invFall);
+    // the fall's abscissa measured from its END: exactly 1 from newDiv2 on (the closed phase: fall = 0 exactly, no separate
+    // factor), below 0 -> 0 before the fall starts; at its first entry it is 0 or one ulp, which 1 - xf^2 does not see.
+    // invFall = 1 / max(newDiv2 - div1, 1/2): a fall of no length closes at once (osc_read)
+    const float xf = sat_f(fma_f(fi - fNewDiv2, invFall, 1.0f));
     const float fall = fma_f(-xf, xf, 1.0f);
-    return (rise * fall) * sat_f(fNewDiv2 - fi);
+    return rise * fall;
 }
-TRM_HD float pulse_table(int i, const Const &C, int newDiv2, float invFall)
-{
-    return pulse_table_f((float)i, (float)C.tableDiv1, C.invDiv1, (float)newDiv2, invFall);
-}
-
 // The excitation stage in two halves (they may run in different waves):
 //   osc_sample  control tracks + 2x oversampled wavetable oscillator -> the two table reads of the
 //               sample and the two amplitudes                              (fp64 tracks live here)
@@ -255,18 +253,20 @@ TRM_HD void osc_read(const Const &C, double axd, double pos1, double pos2, SineL
 {
     int lo1 = (int)pos1, lo2 = (int)pos2;           // 0 .. 511: the position lies in (-1, 511] and the cast truncates (:183)
     float fr1 = (float)(pos1 - (double)lo1), fr2 = (float)(pos2 - (double)lo2);
-    int up1 = (lo1 + 1) & (kTableLen - 1);          // mod0(lower + 1), :185
-    int up2 = (lo2 + 1) & (kTableLen - 1);
     float a0, a1, b0, b1;
     if (C.waveform == 0) {
-        int newDiv2 = C.tableDiv2 - (int)rint_d(axd * C.tnDelta);   // :122
-        float invFall = rcp_f((float)(newDiv2 - C.tableDiv1));
-        const float fDiv1 = (float)C.tableDiv1, fNew = (float)newDiv2;
-        a0 = pulse_table_f((float)lo1, fDiv1, C.invDiv1, fNew, invFall);
-        a1 = pulse_table_f((float)up1, fDiv1, C.invDiv1, fNew, invFall);
-        b0 = pulse_table_f((float)lo2, fDiv1, C.invDiv1, fNew, invFall);
-        b1 = pulse_table_f((float)up2, fDiv1, C.invDiv1, fNew, invFall);
+        // newDiv2 = tableDiv2 - rint(amplitude * tnDelta) (:122), an integer kept in a float
+        const float fDiv1 = (float)C.tableDiv1, fNew = (float)C.tableDiv2 - (float)rint_d(axd * C.tnDelta);
+        const float invFall = rcp_f(fmaxf(fNew - fDiv1, 0.5f));
+        // the upper entry is entry lo + 1 without the wrap: "entry 512" evaluates to entry 0's value, 0 (rise 1, fall closed:
+        // newDiv2 <= tableDiv2 <= 512, build_const)
+        const float f1 = (float)lo1, f2 = (float)lo2;
+        a0 = pulse_table_f(f1, fDiv1, C.invDiv1, fNew, invFall);
+        a1 = pulse_table_f(f1 + 1.0f, fDiv1, C.invDiv1, fNew, invFall);
+        b0 = pulse_table_f(f2, fDiv1, C.invDiv1, fNew, invFall);
+        b1 = pulse_table_f(f2 + 1.0f, fDiv1, C.invDiv1, fNew, invFall);
     } else {
+        const int up1 = (lo1 + 1) & (kTableLen - 1), up2 = (lo2 + 1) & (kTableLen - 1);          // mod0(lower + 1), :185
         a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);
     }
     wa = fma_f(fr1, a1 - a0, a0);
@@ -418,7 +418,10 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
 
 // kFricGain: multiply the frication amplitude by C.fricGain (the streaming kernel instance only: trm_stream_set_mode;
 // the one-shot instances carry no such instruction)
-template <bool kFricGain = false>
+// kSatTaps: "max(., 0)" as the [0, 1] clamp of the FMA that forms the tap -- two operations per tap instead of three; only
+// without the gain (the amplitude is at most 1 then) and only where it pays: the one-voice-per-lane kernel (8 of its 450
+// instructions per sample); the eight-lane kernel's frication wave ran 3 % SLOWER with it (profiles/ab_r03.txt).
+template <bool kFricGain = false, bool kSatTaps = false>
 TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j)
 {
     const float fj = (float)j;
@@ -436,7 +439,8 @@ TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j
     const float fricPos = fma_f(fj, T.fricPosDelta, T.fricPos0);                 // (:676-688)
     for (int i = 0; i < 8; i++) {
         const float dist = fabsf(fricPos - (float)i);
-        K.tap[i] = fmaxf(fma_f(-fricAmp, dist, fricAmp), 0.0f);
+        const float t = fma_f(-fricAmp, dist, fricAmp);
+        K.tap[i] = kSatTaps ? sat_f(t) : fmaxf(t, 0.0f);
     }
 
     // band-pass coefficients (TRMFilters.m:9-17): beta = (1 - t) / (2 (1 + t)), t = tan(pi BW / SR); gamma = (1/2 + beta)
@@ -466,7 +470,7 @@ TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
 {
     Coefs K;
     coef_sample_area(K, T, C, j);
-    coef_sample_fric<kFricGain>(K, T, C, j);
+    coef_sample_fric<kFricGain, !kFricGain>(K, T, C, j);
     return K;
 }
 

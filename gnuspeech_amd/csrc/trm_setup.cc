@@ -199,6 +199,9 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     c.upsample = d.sampleRateRatio >= 1.0;
     c.sampleRateRatioD = d.sampleRateRatio;
     if (c.tableDiv1 < 0 || c.tableDiv2 > 512 || c.tableDiv1 > c.tableDiv2) return TRM_ERANGE;
+    // (tnMax < tnMin moves the closure point PAST tableDiv2 as the amplitude grows; beyond entry 512 the reference writes outside
+    // its table, TRMWavetable.m:117-156)
+    if (c.tnDelta < 0.0 && (double)c.tableDiv2 - c.tnDelta > 512.0) return TRM_ERANGE;
     return TRM_OK;
 }
 
