@@ -1,32 +1,44 @@
 #!/usr/bin/env python3
-"""Per-step work of every pipeline role of workgroup 0 (stamp build with -DTRM_STAMP_TRACE): how much of the step is the
-slowest role of THAT step (what one barrier for all waves pays) against the slowest role on average (what a decoupled
-pipeline would pay).   usage: TRM_STAMP_LIB=.../libtrm_stamp_trace.so step_trace.py [voices] [seconds]"""
+"""What does the per-step barrier cost?  Per-step work cycles of every role of workgroup 0 (a -DTRM_STAMP -DTRM_STAMP_TRACE build of the
+kernels: TRM_STAMP_LIB=...), and three totals over the traced steps:
+  lockstep   sum over steps of the slowest role's work        (what one barrier per step costs at least)
+  elastic-1  every role may run ONE step ahead of the slowest (it starts step s when all have finished s-2): needs every hand-off
+             one step later and two slots deeper than the lockstep pipeline has them -- an upper bound on what hand-shakes could buy
+  free       the busiest role's total                          (unbounded buffering)
+usage: step_trace.py <voices> <seconds> <static|timevarying> <wide|quad|oct>"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["TRM_LIB"] = os.environ.get("TRM_STAMP_LIB") or os.path.join(ROOT, "gnuspeech_amd", "libtrm_stamp_trace.so")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch, cases
+os.environ["TRM_LIB"] = os.environ["TRM_STAMP_LIB"]
+import numpy as np, torch
+import cases
 import gnuspeech_amd as g
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-secs = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-nframes = int(round(secs * 250)) + 1
+V, sec, kind, form = int(sys.argv[1]), float(sys.argv[2]), sys.argv[3], sys.argv[4]
+nframes = int(round(sec * 250)) + 1
+fr = cases.config2_frames(V, nframes=nframes) if kind == "static" else cases.config3_frames(V, nframes=nframes)
 b = g.TRMBatch(g.TRMInputParameters.from_dict(cases.monet_default_params(44100.0)))
-b.set_kernel("quad")
-st = b.prepare_device(cases.config2_frames(V, nframes=nframes))
+b.set_kernel(form)
+st = b.prepare_device(fr)
 for _ in range(2):
     b.synthesize_device(st)
 torch.cuda.synchronize()
 L = g.lib()
-buf = np.zeros(400000 + 7 * 4096, dtype=np.uint64)
+buf = np.zeros(400000 + 8 * 4096, dtype=np.uint64)
 L.trm_debug_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert L.trm_debug_stamps(buf.ctypes.data, buf.size) == 0
-tr = buf[400000:400000 + 6 * 4096].reshape(6, 4096).astype(np.float64)
-n = int((tr[4] > 0).sum())
-tr = tr[:, 8:n - 8]                     # (steady state: without the pipeline's fill and drain)
-names = ["osc", "mix", "area", "fric", "tube", "convert"]
-print("workgroup 0, %d steady steps; work cycles per step: " % tr.shape[1] + ", ".join("%s %.0f +- %.0f" % (names[r], tr[r].mean(), tr[r].std()) for r in range(6)))
-mx = tr.max(axis=0)
-print("mean over steps of the slowest role of the step: %.0f; slowest role on average: %.0f (%s): one barrier for all waves pays %.1f %% for the jitter"
-      % (mx.mean(), tr.mean(axis=1).max(), names[int(tr.mean(axis=1).argmax())], 100.0 * (mx.mean() / tr.mean(axis=1).max() - 1.0)))
-print("which role is the slowest of a step: " + ", ".join("%s %.0f %%" % (names[r], 100.0 * (tr.argmax(axis=0) == r).mean()) for r in range(6)))
+NR = 7 if form == "wide" else 6
+w = buf[400000:400000 + NR * 4096].reshape(NR, 4096).astype(np.float64)
+n = int(min((w[r] > 0).sum() for r in range(NR)))
+w = w[:, 8:n - 8]
+S = w.shape[1]
+print("%s, %d voices: %d traced steps of workgroup 0; mean work per step by role: %s" % (form, V, S, np.round(w.mean(axis=1)).astype(int).tolist()))
+lock = w.max(axis=0).sum()
+free = w.sum(axis=1).max()
+# elastic: role r may start step s when it finished s-1 and every other role finished step s-2 (double buffers, lags of one step folded in)
+t = np.zeros((NR, S + 2))
+for s in range(S):
+    gate = t[:, s].max() if s >= 1 else 0.0      # everyone finished step s-2 (index s holds the finish time of step s-2 ... s offset 2)
+    for r in range(NR):
+        t[r, s + 2] = max(t[r, s + 1], gate) + w[r, s]
+el = t[:, S + 1].max()
+print("lockstep %.0f cycles per step, elastic-1 %.0f (%.1f %% less), free %.0f (%.1f %% less)" % (lock / S, el / S, 100 * (1 - el / lock), free / S, 100 * (1 - free / lock)))
