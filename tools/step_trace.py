@@ -42,3 +42,23 @@ for s in range(S):
         t[r, s + 2] = max(t[r, s + 1], gate) + w[r, s]
 el = t[:, S + 1].max()
 print("lockstep %.0f cycles per step, elastic-1 %.0f (%.1f %% less), free %.0f (%.1f %% less)" % (lock / S, el / S, 100 * (1 - el / lock), free / S, 100 * (1 - free / lock)))
+
+# who is the slowest, and when: share of steps each role is the maximum in, its mean excess over the busiest role's mean there,
+# and the work of each role by position in the control period (steps per period = control period / samples per step)
+names = ["osc", "mix", "coef0", "coef1", "tube", "convert0", "convert1"][:NR] if form == "wide" else ["osc", "mix", "area", "fric", "tube", "convert"]
+am = w.argmax(axis=0)
+busiest = w.mean(axis=1).max()
+for r in range(NR):
+    sel = am == r
+    if sel.any():
+        print("  %-8s slowest in %4.1f %% of the steps, there %5.0f cycles (its mean %5.0f, std %4.0f)" % (names[r], 100 * sel.mean(), w[r, sel].mean(), w[r].mean(), w[r].std()))
+spp = float(b.derived["controlPeriod"]) / {"wide": 2, "quad": 4, "oct": 8}[form]
+if abs(spp - round(spp)) < 1e-9 and spp >= 2:
+    P = int(round(spp))
+    ph = (np.arange(S) + 8) % P
+    print("  mean of the step's maximum by step within the control period (%d steps): %s" % (P, [int(w.max(axis=0)[ph == q].mean()) for q in range(P)]))
+    for r in range(NR):
+        print("    %-8s %s" % (names[r], [int(w[r, ph == q].mean()) for q in range(P)]))
+if "-v" in sys.argv:
+    for s0 in range(200, 264):
+        print("   step %4d  %s   max %s" % (s0 + 8, " ".join("%5d" % int(w[r, s0]) for r in range(NR)), names[int(w[:, s0].argmax())]))
