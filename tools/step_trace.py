@@ -59,6 +59,8 @@ if abs(spp - round(spp)) < 1e-9 and spp >= 2:
     print("  mean of the step's maximum by step within the control period (%d steps): %s" % (P, [int(w.max(axis=0)[ph == q].mean()) for q in range(P)]))
     for r in range(NR):
         print("    %-8s %s" % (names[r], [int(w[r, ph == q].mean()) for q in range(P)]))
+if "--save" in sys.argv:
+    np.save(sys.argv[sys.argv.index("--save") + 1], w)
 if "-v" in sys.argv:
     for s0 in range(200, 264):
         print("   step %4d  %s   max %s" % (s0 + 8, " ".join("%5d" % int(w[r, s0]) for r in range(NR)), names[int(w[:, s0].argmax())]))
