@@ -197,6 +197,18 @@ class TRMBatch:
         """'auto' | 'wide' (one voice per lane) | 'quad' (four lanes per voice) | 'oct' (eight); see include/trm_c_api.h."""
         check(lib().trm_batch_set_kernel(self._h, {"auto": 0, "wide": 1, "quad": 2, "oct": 3}[kernel]))
 
+    def set_time_split(self, periods):
+        """'auto' (default) | 'off' | control periods per segment: cut every utterance in time and run the segments side by
+        side, each from rest a warm-up ahead (include/trm_c_api.h: trm_batch_set_time_split)."""
+        check(lib().trm_batch_set_time_split(self._h, {"auto": -1, "off": 0}.get(periods, periods)))
+
+    @property
+    def last_time_split(self):
+        """(control periods per segment, warm-up control periods) of the last launch; (0, 0) = whole utterances."""
+        p, w = C.c_uint32(), C.c_uint32()
+        check(lib().trm_batch_last_time_split(self._h, C.byref(p), C.byref(w)))
+        return p.value, w.value
+
     def set_timing(self, on):
         """Launch timing on / off; off, synthesize_device is pure stream work and can be captured into a HIP graph."""
         check(lib().trm_batch_set_timing(self._h, int(bool(on))))
@@ -260,5 +272,5 @@ class TRMMultiBatch(TRMBatch):
         raise NotImplementedError("TRMMultiBatch carries the host-buffer entries only (one trm_batch per device inside the library)")
 
     prepare_device = synthesize_device = scale_to_int16_device = prepare_events_device = generate_frames_device = _device_only
-    noise_table = set_kernel = kernel_time_ms = set_timing = _device_only
-    last_kernel = property(_device_only)
+    noise_table = set_kernel = kernel_time_ms = set_timing = set_time_split = _device_only
+    last_kernel = last_time_split = property(_device_only)

@@ -105,6 +105,11 @@ struct trm_batch {
     bool envDownGeneric = false;         // TRM_DOWNSAMPLE_GENERIC, read once at create (tests: the generic down-sampling kernel)
     size_t tubeOffVoices = 0;            // dTubeOff holds pitch * v for v < tubeOffVoices ...
     uint64_t tubeOffPitch = 0;           // ... at this row pitch (down-sampling batches: rebuilt only when either changes)
+    // time-split launches (trm_batch_set_time_split)
+    int splitSetting = TRM_TIME_SPLIT_AUTO;      // AUTO, OFF, or a segment length in control periods
+    uint32_t lastSplitPeriods = 0, lastSplitWarm = 0;      // what the last launch did (0: whole utterances)
+    DevBuf<double> dSegPhase;
+    uint32_t *dGate = nullptr;
 };
 
 struct trm_tube {
@@ -205,6 +210,9 @@ int trm_batch_create(const trm_input_params *params, int device, trm_batch **out
     B_TRY(hipMalloc((void **)&b->dConst, sizeof(trm::Const)));
     B_TRY(hipMemcpy(b->dConst, &b->c, sizeof(trm::Const), hipMemcpyHostToDevice));
     B_TRY(hipMalloc((void **)&b->dNoiseState, 2 * sizeof(double)));
+    B_TRY(hipMalloc((void **)&b->dGate, sizeof(uint32_t)));
+    if (const char *e = getenv("TRM_TIME_SPLIT"))          // off | auto | <control periods per segment> (tests, experiments)
+        b->splitSetting = !strcmp(e, "off") ? TRM_TIME_SPLIT_OFF : !strcmp(e, "auto") ? TRM_TIME_SPLIT_AUTO : atoi(e);
     {
         // Read-only tables: built and uploaded once per process and device (per ratio for the down-sampling rows) and
         // shared by every batch object there -- a fresh tube per utterance (TRMSynthesizer.m:118-136) finds them in place.
@@ -278,6 +286,7 @@ void trm_batch_destroy(trm_batch *b)
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (b->dConst) (void)hipFree(b->dConst);
     if (b->dNoiseState) (void)hipFree(b->dNoiseState);
+    if (b->dGate) (void)hipFree(b->dGate);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -389,6 +398,108 @@ static int ensure_noise(trm_batch *b, uint32_t need, hipStream_t stream)
     return TRM_OK;
 }
 
+// ------------------------------------------------------------------ time-split launches
+// The waveguide forgets: every travelling wave is multiplied by the damping factor once per sample (TRMTubeModel.m:216,
+// :796-829), the end filters, the throat and the frication band-pass are stable one- and two-pole sections, the FIR and
+// the converter are feed-forward, the noise sequence is addressed by its index and the oscillator position is an exact
+// prefix sum.  A tube started from rest therefore agrees with the uninterrupted one after a warm-up: the difference
+// decays like the slowest pole, pole^n.  (Measured against the oracle, tools/timesplit_study.py: with damping^W = 1e-6
+// even a voice with mouth and velum closed -- nothing but the damping factor takes energy out -- is back at the
+// unsplit path's own error, 2e-6 worst sample; open voices get there in half the time.)  An utterance can so be cut in
+// time and its pieces run side by side: what bounds a small or ragged batch is the serial chain of its longest voice.
+namespace {
+struct SplitPlan {
+    uint32_t periods = 0;         // control periods per segment; 0 = whole utterances
+    uint32_t warm = 0;            // warm-up control periods
+    float bwFloor = 0.0f;         // frication bandwidths below this need a longer warm-up: the launch falls back (device-side)
+};
+constexpr double kSplitLogEps = -13.815510557964274;      // ln(1e-6): what is left of the state the warm-up starts without
+}  // namespace
+
+// warm-up (tube samples) after which a tube started from rest has forgotten that it was; 0 = never (a pole on the unit circle)
+static uint32_t split_warm_samples(const trm::Const &c)
+{
+    double pole = fabs((double)c.damping);
+    const double others[] = {fabs((double)c.mCoeff), fabs((double)c.nCoeff), fabs((double)c.tb1)};
+    for (double o : others) pole = o > pole ? o : pole;
+    if (!(pole < 0.99999)) return 0;
+    const double w = kSplitLogEps / log(pole);
+    if (!(w < 1.0e6)) return 0;
+    // + the oscillator FIR's 24 samples of history, the converter's 26-sample window and the pipeline's block granularity
+    return (uint32_t)ceil(w) + 64u;
+}
+
+// predicted launch time, ms per second of speech at Monet's rates (19 750 tube samples): the measured figures of the
+// kernel forms on 256 CUs (profiles/sweep_forms_r03.txt), scaled by the occupancy of the device at hand
+static double unsplit_cost(const trm_batch *b, size_t nvoices, int which)
+{
+    const double cus = b->cus > 0 ? b->cus : 256, vpc = (double)nvoices / cus;
+    if (which == TRM_KERNEL_OCT) return vpc <= 4 ? 2.06 : vpc <= 8 ? 2.24 : 2.37 * (vpc <= 16 ? 1.0 : vpc / 16.0);
+    if (which == TRM_KERNEL_QUAD) return vpc <= 16 ? 3.1 : vpc <= 32 ? 4.0 : 4.0 * vpc / 32.0;
+    return vpc <= 64 ? 6.5 : vpc <= 128 ? 7.8 : 7.8 * vpc / 128.0;
+}
+static double split_cost(const trm_batch *b, uint64_t workgroups)
+{
+    const double cus = b->cus > 0 ? b->cus : 256, w = (double)workgroups / cus;
+    return w <= 1 ? 6.5 : w <= 2 ? 6.5 + 1.3 * (w - 1) : 7.8 * w / 2;
+}
+
+// `which` = the kernel form the launch would take unsplit
+static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, SplitPlan &pl)
+{
+    pl = SplitPlan();
+    const int setting = b->splitSetting;
+    if (setting == TRM_TIME_SPLIT_OFF || !b->c.upsample || max_nframes < 2) return TRM_OK;
+    const uint32_t CP = (uint32_t)b->c.controlPeriod, P = max_nframes - 1;
+    const uint32_t ws = split_warm_samples(b->c);
+    if (ws == 0) {
+        if (setting > 0) return fail(TRM_ERANGE, "time split: the tube never forgets (loss factor %g %%)", b->params.lossFactor);
+        return TRM_OK;
+    }
+    const uint32_t warm = (ws + CP - 1) / CP;
+    uint32_t periods = 0;
+    if (setting > 0) periods = (uint32_t)setting;
+    else {
+        // AUTO: the segment length with the shortest predicted launch, taken when it beats whole utterances by a margin
+        const double whole = unsplit_cost(b, nvoices, which) * P;
+        double best = whole * 0.85;
+        const uint64_t wgPerSeg = (nvoices + 63) / 64;
+        for (uint32_t nseg = 2; nseg <= 512 && nseg <= P; nseg++) {
+            const uint32_t sp = (P + nseg - 1) / nseg;
+            if ((uint64_t)sp * CP < 512) break;                          // (segments of a few hundred samples: all warm-up)
+            const double t = split_cost(b, wgPerSeg * ((P + sp - 1) / sp)) * (sp + warm) * 1.03 + 0.03 * 19750.0 / CP;
+            if (t < best) { best = t; periods = sp; }
+        }
+    }
+    if (periods == 0 || periods >= P) return TRM_OK;                     // one segment is the whole utterance
+    pl.periods = periods;
+    pl.warm = warm;
+    {
+        // the frication band-pass (TRMFilters.m:9-29) has poles of radius sqrt(2 beta), 2 beta = (1 - t) / (1 + t),
+        // t = tan(pi BW / SR): the bandwidth at which the warm-up leaves 1e-6 of its memory
+        const double r2 = exp(2.0 * kSplitLogEps / (double)(warm * CP - 64u));
+        const double t = (1.0 - r2) / (1.0 + r2);
+        pl.bwFloor = (float)((double)b->d.sampleRate * atan(t) / 3.14159265358979323846);
+    }
+    return TRM_OK;
+}
+
+int trm_batch_set_time_split(trm_batch *b, int periods)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (periods < TRM_TIME_SPLIT_AUTO) return fail(TRM_EINVAL, "time split: %d", periods);
+    b->splitSetting = periods;
+    return TRM_OK;
+}
+
+int trm_batch_last_time_split(const trm_batch *b, uint32_t *periods, uint32_t *warm_periods)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (periods) *periods = b->lastSplitPeriods;
+    if (warm_periods) *warm_periods = b->lastSplitWarm;
+    return TRM_OK;
+}
+
 int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_frames, const uint64_t *d_frame_offset,
                                 const uint32_t *d_nframes, uint32_t max_nframes, float *d_out,
                                 const uint64_t *d_out_offset, uint32_t *d_number_samples, float *d_max_sample,
@@ -483,6 +594,36 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // above ~0.8 / 1.2 kHz for an adult tube): those one-shot forms stage the control frames in LDS a period ahead, and a
     // period must hold three (two) of their steps
     if (which == TRM_KERNEL_QUAD && b->c.controlPeriod < 24) which = TRM_KERNEL_WIDE;
+    // Time split (above): the utterances cut into segments that run side by side in the one-voice-per-lane form.  A form
+    // the caller asked for by name is run as asked (whole utterances) unless the split was asked for by name too.
+    SplitPlan pl;
+    const bool formByName = b->kernel != TRM_KERNEL_AUTO || b->envKernel != TRM_KERNEL_AUTO;
+    if (!(formByName && b->splitSetting <= 0) && (rc = plan_time_split(b, nvoices, max_nframes, which, pl))) return rc;
+    b->lastSplitPeriods = pl.periods;
+    b->lastSplitWarm = pl.periods ? pl.warm : 0;
+    if (pl.periods) {
+        const uint32_t nseg = (max_nframes - 1 + pl.periods - 1) / pl.periods;
+        const uint32_t wgPerSeg = (uint32_t)((nvoices + 63) / 64);
+        if ((uint64_t)nseg * wgPerSeg > 0x7FFFFFFFull / 64) return fail(TRM_ERANGE, "time split: too many segments");
+        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * 64))) return rc;
+        HIP_TRY(hipMemsetAsync(b->dGate, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(d_max_sample, 0, nvoices * sizeof(float), stream));
+        trm::PhaseArgs ph;
+        ph.frames = d_frames; ph.frame_offset = d_frame_offset; ph.nframes = d_nframes;
+        ph.seg_phase = b->dSegPhase.p; ph.gate = b->dGate; ph.bw_floor = pl.bwFloor;
+        ph.nvoices = (uint32_t)nvoices; ph.max_nframes = max_nframes; ph.nseg = nseg;
+        ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg;
+        HIP_TRY(trm::launch_phase(b->c, ph, stream));
+        trm::TubeArgs sa = a;
+        sa.seg_periods = pl.periods; sa.seg_warm = pl.warm; sa.seg_wg_per_seg = wgPerSeg; sa.seg_grid = nseg * wgPerSeg;
+        sa.seg_phase = b->dSegPhase.p;
+        sa.gate = b->dGate; sa.gate_want = 0;
+        HIP_TRY(trm::launch_tube(b->c, sa, stream));
+        // ... and, should the pre-pass have found a track the warm-up does not cover, whole utterances (the launch below
+        // returns at once otherwise)
+        a.gate = b->dGate; a.gate_want = 1;
+        which = TRM_KERNEL_WIDE;
+    }
     b->lastKernel = which;
     if (which == TRM_KERNEL_OCT)
         HIP_TRY(trm::launch_tube_oct(b->c, a, stream));

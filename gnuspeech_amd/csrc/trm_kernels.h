@@ -44,7 +44,36 @@ struct TubeArgs {
     //                  converter outputs k_base <= k < k_end (global indices).  Same for every voice of the launch.
     float *stream_state;
     uint32_t stream_flags, stream_n_base, stream_k_base, stream_k_end;
+    // Time-split launches (trm_tube_kernel<kModeSegments> only; seg_periods == 0 otherwise).  An utterance is cut every
+    // seg_periods control periods; workgroup w runs segment w / seg_wg_per_seg of the voices 64 * (w % seg_wg_per_seg) ..+63
+    // from REST, seg_warm control periods before the segment's first one (the tube forgets like its slowest pole:
+    // trm_capi.cc plan_time_split), and emits the converter outputs whose read position lies in the segment proper.  What a
+    // segment cannot reconstruct from the frames is the oscillator position: seg_phase[q * 64 * seg_wg_per_seg + v] is the
+    // (wrapped) advance of voice v's oscillator between the warm-up starts of segments q - 1 and q (trm_phase_kernel);
+    // the kernel sums q = 1 .. its own segment (exact sums: osc_increment).  max_sample is folded with an atomic max
+    // (zeroed by the launcher), number_samples written by segment 0.
+    uint32_t seg_periods = 0, seg_warm = 0, seg_wg_per_seg = 0;
+    uint32_t seg_grid = 0;            // workgroups of the launch: seg_wg_per_seg * (segments of the longest voice)
+    const double *seg_phase = nullptr;
+    // Device-side choice between two launches of one batch (time-split vs whole utterances): a kernel with a gate returns
+    // at once unless (*gate != 0) == gate_want.  Null: no gate.
+    const uint32_t *gate = nullptr;
+    uint32_t gate_want = 0;
 };
+
+// trm_phase_kernel: the oscillator advances a time-split launch starts from, and the guard that decides whether the batch
+// may be split at all: *gate is set when a frame's frication bandwidth lies below bw_floor (the band-pass then remembers
+// longer than the warm-up; whole-utterance launch instead).  `nseg` = segments of the longest voice.
+struct PhaseArgs {
+    const float *frames;
+    const uint64_t *frame_offset;
+    const uint32_t *nframes;
+    double *seg_phase;
+    uint32_t *gate;
+    float bw_floor;
+    uint32_t nvoices, max_nframes, nseg, seg_periods, seg_warm, seg_wg_per_seg;
+};
+hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream);
 
 struct ScaleArgs {
     const float *pcm;

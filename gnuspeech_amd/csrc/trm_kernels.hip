@@ -111,9 +111,17 @@ __global__ void trm_noise_kernel(float *lp, uint32_t from, uint32_t to, double *
 //   [58..68] filter memories            [72..103] the last 32 tube samples (the converter's history)
 // stored per workgroup as [field][lane]: field i of the workgroup's lane l at stream_state[(wg * kStreamFloats + i) * 64 + l]
 // (trm_quad.hip's records are voice-major); the buffer holds kStreamFloats floats per voice, voices rounded up to 64.
-template <bool kStream>
+// kMode: kModeOneShot | kModeStream (above) | kModeSegments: a time-split launch (trm_kernels.h, TubeArgs::seg_*): the workgroup
+// runs ONE segment of its 64 voices from rest, a warm-up ahead of the segment's first control period; like a stream chunk
+// its tube samples and converter outputs keep their global indices (nBase, kBase -- here per workgroup), unlike one it
+// neither restores nor saves state: only the oscillator position is handed in.
+constexpr int kModeOneShot = 0, kModeStream = 1, kModeSegments = 2;
+template <int kMode>
 __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const C, const TubeArgs A)
 {
+    constexpr bool kStream = kMode == kModeStream, kSeg = kMode == kModeSegments;
+    // (two launches of one batch, one of which runs: TubeArgs::gate)
+    if (A.gate && ((*A.gate != 0u) ? 1u : 0u) != A.gate_want) return;
     __shared__ __attribute__((aligned(16))) float4 sW[2 * kTB * kWave];          // osc -> mix: {wa, wb, ax, ah1}
     __shared__ __attribute__((aligned(16))) float4 sX[2 * kTB * kWave];          // mix -> tube: excitation per sample
     __shared__ __attribute__((aligned(16))) float4 sK[2 * kTB * kKQuads * kWave]; // coefficients per sample
@@ -135,21 +143,44 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     int role = 0;
     for (int i = 0; i < kRoles; i++) role = waveIdx == i ? rolePerm[i] : role;
     const uint32_t wg = A.wg_base + blockIdx.x;          // (a large batch is launched in slices: launch_tube)
-    const uint32_t vRaw = wg * kWave + lane;
+    // time-split: workgroup -> (segment, block of 64 voices)
+    const uint32_t seg = kSeg ? wg / A.seg_wg_per_seg : 0u;
+    const uint32_t vblock = kSeg ? wg - seg * A.seg_wg_per_seg : wg;
+    const uint32_t vRaw = vblock * kWave + lane;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
-
-    const uint32_t nfr = min(A.nframes[v], A.max_nframes);
-    const uint32_t nfrMax = wave_max_u32(nfr);          // same 64 voices in every wave of the group
     const uint32_t CP = (uint32_t)C.controlPeriod;
     const uint32_t inc = C.timeRegisterIncrement;
+    // converter outputs with a read position before tube sample `end`: k < outputs_before(end) (trm_capi.cc outputs_through)
+    auto outputs_before = [&](uint64_t end) { return end == 0 ? 0u : (uint32_t)(((end << 16) - 1) / inc + 1); };
+
+    const uint32_t nfrAll = min(A.nframes[v], A.max_nframes);
+    // the frames this launch runs for this lane: the utterance's, or those of the workgroup's segment with its warm-up
+    uint32_t nfr = nfrAll, segFrame0 = 0, segOutEnd = 0;
+    bool segLast = true;
+    if (kSeg) {
+        const uint32_t nper = nfrAll > 0 ? nfrAll - 1 : 0;
+        const uint32_t pLo = seg * A.seg_periods;
+        segFrame0 = pLo > A.seg_warm ? pLo - A.seg_warm : 0u;                      // (uniform)
+        if (seg > 0 && pLo >= nper) nfr = 0;                                       // the voice ended before this segment
+        else if (nfrAll > 0) {
+            const uint32_t pHi = pLo + A.seg_periods < nper ? pLo + A.seg_periods : nper;
+            nfr = pHi - segFrame0 + 1;
+            segLast = pHi == nper;
+            segOutEnd = outputs_before((uint64_t)pHi * CP);                        // (used when the voice goes on)
+        }
+    }
+    const uint32_t nfrMax = wave_max_u32(nfr);          // same 64 voices in every wave of the group
     const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
     // (nfrMax-1) control periods, then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93).
     // Lanes whose utterance is shorter than the group's longest keep stepping on their last frame;
     // the tube stage hands zeros to the converter past a voice's own end.
     const bool sFirst = !kStream || (A.stream_flags & 1u), sLast = !kStream || (A.stream_flags & 2u);
     const bool sHold = kStream && (A.stream_flags & 4u);       // TRAcT's loop order: a period runs on the frame that ends it, held
-    const uint32_t nBase = kStream ? A.stream_n_base : 0u, kBase = kStream ? A.stream_k_base : 0u;
+    // (segments: a workgroup's lanes either end inside the segment -- their flush follows -- or run to its end: nTotal
+    // carries the flush's 2*pad samples either way, lanes that go on stop emitting at segOutEnd)
+    const uint32_t nBase = kStream ? A.stream_n_base : kSeg ? segFrame0 * CP : 0u;
+    const uint32_t kBase = kStream ? A.stream_k_base : kSeg ? outputs_before((uint64_t)seg * A.seg_periods * CP) : 0u;
     // this voice's state record: per workgroup a block of [kStreamFloats fields][64 lanes] floats -- a wave's 64 lanes touch
     // 64 consecutive floats per field (voice-major records cost 64 cache lines per field and instruction) and a field is a
     // CONSTANT 256 bytes from the one before (one base address per lane: per-field 64-bit strides cost the streaming
@@ -184,7 +215,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     // long as the 32*inc/2^16 tube samples it spans)
     const uint32_t nSteps = nTotal > 0 ? (nTotal + kTB - 1) / kTB + 3 + 2 * ((kCvtCols * inc / 65536u) / kTB + 2) + 4 : 0;
     // a voice without frames (a silent no-op, TRMTubeModel.m:274-277) reads row 0 of the buffer
-    const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
+    const float *frames = A.frames + (nfr > 0 ? (A.frame_offset[v] + segFrame0) * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
 
     for (int i = threadIdx.x; i < kWave * kYStride; i += kWave * kRoles) sY[i] = 0.0f;   // 25 zeros of pre-roll
@@ -208,6 +239,16 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         OscState S;
         ExciteTrack T;
         S.oscPos = (kStream && !sFirst) ? st_load_f64() : 0.0;
+        if (kSeg) {
+            // the oscillator's position at the warm-up start: the wrapped advances between the warm-up starts of the
+            // segments so far, summed in order (every term and sum a multiple of 2^-30 below 2^10: exact)
+            const double *ph = A.seg_phase + vRaw;
+            const size_t pitch = (size_t)A.seg_wg_per_seg * kWave;
+            for (uint32_t q = 1; q <= seg; q++) {
+                const double t = S.oscPos + ph[q * pitch];
+                S.oscPos = t > 511.0 ? t - 512.0 : t;
+            }
+        }
         // (both frames of a control period are fetched when it starts, once per ~80 samples: carrying the current frame
         // to the next boundary in registers costs a register-to-register copy of it per STEP, the loop's phi nodes)
         auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
@@ -241,8 +282,9 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     } else if (role == 1) {
         // ------------------------------------------------------------ mix: FIR + noise mixing, block i-1 at step i
         __builtin_amdgcn_s_setprio(TRM_PRIO_MIX);
+        const float *const lpNoise = A.lp_noise + (kSeg ? nBase : 0u);      // (a stream's pointer arrives advanced)
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
-            dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
+            dma4(lpNoise + nFirst + lane, &sNoise[half * kNoiseHalf]);
         };
         FirState S;
         for (int i = 0; i < 24; i++) S.fir[i] = (kStream && !sFirst) ? st[2 + i] : 0.f;
@@ -419,9 +461,14 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
         }
         if (kStream) noutLane = A.stream_k_end - kBase;
+        uint32_t noutAll = 0;                   // (segments: the whole utterance's count)
+        if (kSeg) {
+            if (nfrAll > 0) noutAll = (uint32_t)((((uint64_t)(nfrAll - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);
+            noutLane = nfr > 0 ? (segLast ? noutAll : segOutEnd) - kBase : 0u;
+        }
         if (!laneValid) noutLane = 0;
         // per-voice values stay in the VGPRs of lane == voice and are broadcast per row with v_readlane
-        const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v]);
+        const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v] + (kSeg ? kBase : 0u));
         const uint32_t myLo = (uint32_t)myOut, myHi = (uint32_t)(myOut >> 32);
         const uint32_t noutMax = wave_max_u32(noutLane);
         // (a down-sampling batch is converted by trm_downsample_kernel: no blocks here, only the barriers)
@@ -552,14 +599,68 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             if (lane == 2 * r) myMax = lowHalf;
             if (lane == 2 * r + 1) myMax = highHalf;
         }
-        const uint32_t ov = wg * kWave + 32 * cw + (lane & 31);
-        const uint32_t nov = __builtin_amdgcn_ds_bpermute(4 * (32 * cw + (lane & 31)), noutLane);
+        const uint32_t ov = vblock * kWave + 32 * cw + (lane & 31);
+        const uint32_t nov = __builtin_amdgcn_ds_bpermute(4 * (32 * cw + (lane & 31)), kSeg ? noutAll : noutLane);
         if (lane < 32 && ov < A.nvoices && C.upsample) {
-            A.number_samples[ov] = nov;
-            A.max_sample[ov] = myMax;
+            if (kSeg) {
+                // (non-negative floats order like their bit patterns; max_sample was zeroed by the launcher)
+                if (seg == 0) A.number_samples[ov] = nov;
+                if (myMax > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(&A.max_sample[ov]), __float_as_uint(myMax));
+            } else {
+                A.number_samples[ov] = nov;
+                A.max_sample[ov] = myMax;
+            }
         }
         return;
     }
+}
+
+// Prefix pass of a time-split launch (TubeArgs::seg_*).  Thread (q, v), q = 0 .. nseg - 1, walks voice v's control periods
+// between the warm-up starts of segments q and q + 1 (the last q: to the utterance's end):
+//   * the oscillator's advance over them -- the same track set-up, increments and wraps as osc_sample, position only
+//     (TRMWavetable.m:165-181) -- goes to seg_phase[q + 1][v]: the tube kernel's segment s sums entries 1 .. s;
+//   * a frame whose frication bandwidth lies below bw_floor sets *gate: that band-pass remembers longer than the
+//     warm-up, and the batch runs as whole utterances instead (TubeArgs::gate).
+__global__ __launch_bounds__(256) void trm_phase_kernel(const Const C, const PhaseArgs P)
+{
+    const uint32_t lanes = P.seg_wg_per_seg * kWave;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = idx / lanes, v = idx - q * lanes;
+    if (q >= P.nseg || v >= P.nvoices) return;
+    const uint32_t nfr = min(P.nframes[v], P.max_nframes);
+    const uint32_t nper = nfr > 0 ? nfr - 1 : 0, CP = (uint32_t)C.controlPeriod;
+    auto warm_start = [&](uint32_t sgm) {
+        const uint32_t p = sgm * P.seg_periods;
+        return p > P.seg_warm ? p - P.seg_warm : 0u;
+    };
+    uint32_t lo = warm_start(q), hi = q + 1 < P.nseg ? warm_start(q + 1) : nper;
+    lo = lo < nper ? lo : nper;
+    hi = hi < nper ? hi : nper;
+    const float *frames = P.frames + P.frame_offset[v] * 16;
+    bool narrow = false;
+    double pos = 0.0;
+    float prev[4], cur[4];
+    if (nfr > 0) {
+        load_frame(frames, lo, cur, 1);
+        narrow = frames[(size_t)lo * 16 + 6] < P.bw_floor;
+    }
+    for (uint32_t f = lo + 1; f <= hi; f++) {
+        for (int i = 0; i < 4; i++) prev[i] = cur[i];
+        load_frame(frames, f, cur, 1);
+        narrow = narrow || frames[(size_t)f * 16 + 6] < P.bw_floor;
+        ExciteTrack T;
+        excite_track_setup(T, C, prev, cur);
+        for (uint32_t j = 0; j < CP; j++) {
+            const double inc = osc_increment(T.f0, C);
+            double p1 = pos + inc;
+            p1 = p1 > 511.0 ? p1 - 512.0 : p1;
+            double p2 = p1 + inc;
+            pos = p2 > 511.0 ? p2 - 512.0 : p2;
+            T.f0 *= T.f0Ratio;
+        }
+    }
+    if (q + 1 < P.nseg) P.seg_phase[(size_t)(q + 1) * lanes + v] = pos;
+    if (narrow) atomicOr(P.gate, 1u);
 }
 
 // Down-sampling branch of the converter (TRMSampleRateConverter.m:234-297): one workgroup per voice,
@@ -716,12 +817,15 @@ __global__ __launch_bounds__(256) void trm_int16_kernel(const ScaleArgs S)
 }
 
 // out[v * pitch + i] *= g for i < count; mx[v] *= g  (streams in TRAcT's loop order: tube.c:1177's x100)
-__global__ __launch_bounds__(256) void trm_gain_kernel(float *out, size_t pitch, uint32_t count, float *mx, float g)
+__global__ __launch_bounds__(256) void trm_gain_kernel(float *out, size_t pitch, uint32_t count, uint32_t nvoices, float *mx, float g)
 {
-    float *row = out + (size_t)blockIdx.y * pitch;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) row[i] *= g;
-    if (i == 0 && mx) mx[blockIdx.y] *= g;
+    // (voices on a stride of gridDim.y: a grid's y extent ends at 65535, wide streams carry millions of voices)
+    for (uint32_t v = blockIdx.y; v < nvoices; v += gridDim.y) {
+        float *row = out + (size_t)v * pitch;
+        if (i < count) row[i] *= g;
+        if (i == 0 && mx) mx[v] *= g;
+    }
 }
 
 // ---------------------------------------------------------------- launchers (host)
@@ -734,7 +838,9 @@ hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hi
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
-    const uint32_t grid = (a.nvoices + kWave - 1) / kWave;
+    // (time-split: one workgroup per segment and block of 64 voices; seg_wg_per_seg * segments, set by the caller in wg_base's
+    // place holder `seg_grid`)
+    const uint32_t grid = a.seg_periods ? a.seg_grid : (a.nvoices + kWave - 1) / kWave;
     // A grid of more than two rounds of resident workgroups (2 per CU) runs measurably slower per workgroup than its first
     // two rounds (MI355X, 256 CUs: 1024 workgroups 18.1 ms, 1536: 32.6, 2048: 40.6 -- profiles/ab_r03.txt): the
     // batch goes out in slices of `slice` workgroups, back to back on the stream.  TRM_WIDE_SLICE overrides (0 = one launch).
@@ -746,10 +852,19 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
     for (uint32_t base = 0; base < grid;) {
         const uint32_t n = slice == 0 ? grid - base : (grid - base < slice ? grid - base : slice);
         s.wg_base = base;
-        if (a.stream_state) hipLaunchKernelGGL(trm_tube_kernel<true>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
-        else hipLaunchKernelGGL(trm_tube_kernel<false>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
+        if (a.seg_periods) hipLaunchKernelGGL(trm_tube_kernel<kModeSegments>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
+        else if (a.stream_state) hipLaunchKernelGGL(trm_tube_kernel<kModeStream>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
+        else hipLaunchKernelGGL(trm_tube_kernel<kModeOneShot>, dim3(n), dim3(kWave * kRoles), 0, stream, c, s);
         base += n;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream)
+{
+    if (a.nvoices == 0 || a.nseg == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)a.nseg * a.seg_wg_per_seg * kWave;
+    hipLaunchKernelGGL(trm_phase_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }
 
@@ -757,7 +872,7 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 int tube_kernel_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel<false>, kWave * kRoles, 0) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trm_tube_kernel<kModeOneShot>, kWave * kRoles, 0) != hipSuccess) return -1;
     return n;
 }
 
@@ -788,7 +903,8 @@ hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stre
 hipError_t launch_gain(float *out, size_t pitch, uint32_t count, uint32_t nvoices, float *mx, float g, hipStream_t stream)
 {
     if (nvoices == 0 || count == 0) return hipSuccess;
-    hipLaunchKernelGGL(trm_gain_kernel, dim3((count + 255) / 256, nvoices), dim3(256), 0, stream, out, pitch, count, mx, g);
+    hipLaunchKernelGGL(trm_gain_kernel, dim3((count + 255) / 256, nvoices < 32768u ? nvoices : 32768u), dim3(256), 0, stream, out, pitch, count,
+                       nvoices, mx, g);
     return hipGetLastError();
 }
 

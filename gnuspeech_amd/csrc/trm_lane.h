@@ -136,6 +136,8 @@ struct Const {
     // glottal pulse table geometry (TRMWavetable.m:71-75)
     int32_t tableDiv1, tableDiv2;
     float invDiv1;
+    float riseBias;             // 0; 1 when tableDiv1 == 0: the rise has no entries (TRMWavetable.m:81 loops zero times) and
+                                // its factor in pulse_table_f must be exactly 1 everywhere
     double tnDelta;
     double basicIncrement;      // 512 / sampleRate
     double invControlPeriodD;
@@ -217,10 +219,10 @@ TRM_HD float amplitude_f(float db)
 // The three regions without a compare or a select: with x and xf clamped to [0, 1] the rise polynomial is exactly 1 from
 // the end of the rise on and the fall exactly 1 before its start, so the entry is their PRODUCT (one factor is always
 // exactly 1: the product is the other one, bit for bit); the closed phase is the fall's clamp at 1.  fi = the entry's index as a float.
-TRM_HD float pulse_table_f(float fi, float fDiv1, float invDiv1, float fNewDiv2, float invFall)
+TRM_HD float pulse_table_f(float fi, float riseBias, float invDiv1, float fNewDiv2, float invFall)
 {
-    (void)fDiv1;
-    const float x = sat_f(fi * invDiv1);
+    // (riseBias is 0 -- the FMA is then the exact product fi / div1 -- except for a pulse without a rise, tp ~ 0, where it is 1)
+    const float x = sat_f(fma_f(fi, invDiv1, riseBias));
     const float rise = x * x * fma_f(-2.0f, x, 3.0f);
     // the fall's abscissa measured from its END: exactly 1 from newDiv2 on (the closed phase: fall = 0 exactly, no separate
     // factor), below 0 -> 0 before the fall starts; at its first entry it is 0 or one ulp, which 1 - xf^2 does not see.
@@ -261,10 +263,10 @@ TRM_HD void osc_read(const Const &C, double axd, double pos1, double pos2, SineL
         // the upper entry is entry lo + 1 without the wrap: "entry 512" evaluates to entry 0's value, 0 (rise 1, fall closed:
         // newDiv2 <= tableDiv2 <= 512, build_const)
         const float f1 = (float)lo1, f2 = (float)lo2;
-        a0 = pulse_table_f(f1, fDiv1, C.invDiv1, fNew, invFall);
-        a1 = pulse_table_f(f1 + 1.0f, fDiv1, C.invDiv1, fNew, invFall);
-        b0 = pulse_table_f(f2, fDiv1, C.invDiv1, fNew, invFall);
-        b1 = pulse_table_f(f2 + 1.0f, fDiv1, C.invDiv1, fNew, invFall);
+        a0 = pulse_table_f(f1, C.riseBias, C.invDiv1, fNew, invFall);
+        a1 = pulse_table_f(f1 + 1.0f, C.riseBias, C.invDiv1, fNew, invFall);
+        b0 = pulse_table_f(f2, C.riseBias, C.invDiv1, fNew, invFall);
+        b1 = pulse_table_f(f2 + 1.0f, C.riseBias, C.invDiv1, fNew, invFall);
     } else {
         const int up1 = (lo1 + 1) & (kTableLen - 1), up2 = (lo2 + 1) & (kTableLen - 1);          // mod0(lower + 1), :185
         a0 = sineTab(lo1); a1 = sineTab(up1); b0 = sineTab(lo2); b1 = sineTab(up2);

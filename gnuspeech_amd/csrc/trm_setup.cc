@@ -190,6 +190,7 @@ int build_const(const trm_input_params &p, Const &c, trm_derived &d)
     c.tableDiv1 = (int32_t)rint(512 * (p.tp / 100.0));                   // TRMWavetable.m:71-75
     c.tableDiv2 = (int32_t)rint(512 * ((p.tp + p.tnMax) / 100.0));
     c.invDiv1 = c.tableDiv1 > 0 ? (float)(1.0 / c.tableDiv1) : 0.0f;
+    c.riseBias = c.tableDiv1 > 0 ? 0.0f : 1.0f;                          // no rise entries: the table is the fall alone (:81-96)
     c.tnDelta = rint(512 * ((p.tnMax - p.tnMin) / 100.0));
     c.basicIncrement = 512.0 / (double)d.sampleRate;
     for (int i = 0; i < kFirUnique; i++) c.fir[i] = (float)kFirHalf[i];

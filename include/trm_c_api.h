@@ -370,6 +370,30 @@ enum { TRM_KERNEL_AUTO = 0, TRM_KERNEL_WIDE = 1, TRM_KERNEL_QUAD = 2, TRM_KERNEL
 int  trm_batch_set_kernel(trm_batch *batch, int kernel);
 int  trm_batch_last_kernel(const trm_batch *batch);
 
+/* Time split.  -[TRMTubeModel synthesize] (TRMTubeModel.m:272-361) is a serial recurrence per voice, so a batch of a few
+ * long utterances (GnuTTSServer's one tube per sentence, PhoneToSpeech.m:66-88) lasts as long as its longest voice
+ * whatever the machine.  But the tube forgets: every travelling wave is multiplied by dampingFactor = 1 - lossFactor/100
+ * once per sample (:216), the end filters, throat and frication band-pass are stable filters, the oscillator FIR and the
+ * converter are feed-forward, the noise is a fixed sequence and the oscillator position an exact prefix sum.  A time-split
+ * launch cuts every utterance into segments of `periods` control periods and runs them side by side, each from rest a
+ * warm-up ahead of its first period; the warm-up is chosen by the library so that 1e-6 of the forgotten state is left
+ * (damping^W <= 1e-6: 35 control periods at Monet's defaults; measured against the oracle in tools/timesplit_study.py
+ * and by the parity tests at the one tolerance, 1e-5).  numberSamples and the sample positions are exact as always.
+ *   TRM_TIME_SPLIT_AUTO (default)  the library splits when its launch-time model says so (a form set by name with
+ *                                  trm_batch_set_kernel / TRM_TUBE_KERNEL runs whole utterances);
+ *   TRM_TIME_SPLIT_OFF             whole utterances always;
+ *   periods > 0                    segments of that many control periods (TRM_ERANGE when the tube never forgets:
+ *                                  lossFactor 0).
+ * Down-sampling batches (tube rate above the output rate) are never split.  A control track whose frication bandwidth
+ * falls below what the warm-up covers (some tens of Hz; Monet's minimum is 250) is found on the device before the launch
+ * and the batch then runs as whole utterances -- the call stays asynchronous either way.  The environment variable
+ * TRM_TIME_SPLIT=off|auto|<periods>, read when a batch object is created, sets the default (diagnostics, tests).
+ * trm_batch_last_time_split: what the last launch was set up with (periods 0 = whole utterances).
+ * No reference counterpart. */
+enum { TRM_TIME_SPLIT_AUTO = -1, TRM_TIME_SPLIT_OFF = 0 };
+int  trm_batch_set_time_split(trm_batch *batch, int periods);
+int  trm_batch_last_time_split(const trm_batch *batch, uint32_t *periods, uint32_t *warm_periods);
+
 /* Average device time (ms) of the tube kernel launches since the last call, measured
  * with hipEvents on the launch stream; resets the accumulator.  Used by bench.py. */
 int  trm_batch_kernel_time_ms(trm_batch *batch, double *total_ms, uint32_t *launches);

@@ -88,6 +88,95 @@ extern "C" int trm_emul_synthesize_tract(const trm_input_params *p, const float 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Time-split synthesis (the host model of trm_kernels.hip's segment instance): the utterance is cut every `segPeriods`
+// control periods; every segment after the first starts from REST `warmPeriods` control periods early -- only the
+// oscillator position is the true one (an exact prefix sum, osc_increment) and the noise sequence is addressed by its
+// index -- and the converter outputs whose read position lies in the segment proper are taken from it.  What the warm-up
+// forgets decays like the tube's slowest pole (damping^n for a closed tract); tests/test_quad_model.py and
+// tools/timesplit_study.py measure it against the oracle.
+extern "C" int trm_emul_synthesize_split(const trm_input_params *p, const float *frames, size_t nframes,
+                                         float *out, size_t cap, uint32_t *nout, float *maxv, uint32_t segPeriods, uint32_t warmPeriods)
+{
+    Const C;
+    trm_derived d;
+    int rc = build_const(*p, C, d);
+    if (rc) return rc;
+    if (!C.upsample || segPeriods == 0) return TRM_ERANGE;
+    static std::vector<float> rows;
+    if (rows.empty()) build_src_rows(rows);
+    *nout = 0; *maxv = 0.f;
+    if (nframes == 0) return TRM_OK;
+    const size_t CP = (size_t)C.controlPeriod, nper = nframes - 1, ntube = nper * CP;
+    const uint32_t inc = C.timeRegisterIncrement;
+    std::vector<float> lp(ntube + 1);
+    {
+        double seed = 0.7892347, x1 = 0.0;
+        for (size_t i = 0; i < ntube; i++) {
+            double prod = seed * 377.0;
+            seed = prod - (int)prod;
+            double nz = seed - 0.5;
+            lp[i] = (float)(nz + x1);
+            x1 = nz;
+        }
+    }
+    auto sineLookup = [&](int i) { return sine_table(i); };
+    auto wrap = [](double v) { return v > 511.0 ? v - 512.0 : v; };
+    // oscillator position at the start of every control period (what the device's prefix pass computes)
+    std::vector<double> phase(nper + 1, 0.0);
+    {
+        ExciteTrack T;
+        double pos = 0.0;
+        for (size_t f = 1; f <= nper; f++) {
+            excite_track_setup(T, C, frames + 16 * (f - 1), frames + 16 * f);
+            for (size_t j = 0; j < CP; j++) {
+                const double i2 = osc_increment(T.f0, C);
+                pos = wrap(wrap(pos + i2) + i2);
+                T.f0 *= T.f0Ratio;
+            }
+            phase[f] = pos;
+        }
+    }
+    const uint64_t total = count_outputs(d, ntube);
+    auto outputs_through = [&](uint64_t endSample) { return endSample == 0 ? 0ull : ((endSample << 16) - 1) / inc + 1; };
+    float mx = 0.f;
+    const size_t nseg = nper == 0 ? 1 : (nper + segPeriods - 1) / segPeriods;
+    for (size_t sg = 0; sg < nseg; sg++) {
+        const size_t pLo = sg * segPeriods, pHi = pLo + segPeriods < nper ? pLo + segPeriods : nper;
+        const size_t pStart = pLo > warmPeriods ? pLo - warmPeriods : 0;
+        const size_t nBase = pStart * CP, nLocal = (pHi - pStart) * CP;
+        const bool last = sg + 1 == nseg;
+        // local tube-rate signal: 25 positions of pre-roll (zeros), the samples, the flush zeros
+        std::vector<float> sig(25 + nLocal + 2 * C.padSize + 8, 0.0f);
+        ExciteState ES; ExciteTrack ET; CoefTrack CT; TubeState TS;
+        excite_reset(ES); tube_reset(TS);
+        ES.oscPos = phase[pStart];
+        size_t n = 0;
+        for (size_t f = pStart + 1; f <= pHi; f++) {
+            excite_track_setup(ET, C, frames + 16 * (f - 1), frames + 16 * f);
+            coef_track_setup(CT, C, frames + 16 * (f - 1), frames + 16 * f);
+            for (int j = 0; j < C.controlPeriod; j++) {
+                Excitation E = excite_sample(ES, ET, C, C.fir, j, lp[nBase + n], sineLookup);
+                Coefs K = coef_sample(CT, C, j);
+                sig[25 + n] = tube_sample(TS, C, E, K);
+                n++;
+            }
+        }
+        const uint64_t kLo = outputs_through(pLo * CP), kHi = last ? total : outputs_through(pHi * CP);
+        for (uint64_t k = kLo; k < kHi; k++) {
+            const uint32_t ph = src_phase((uint32_t)k, inc);
+            const uint64_t e = ((uint64_t)k * inc) >> 16;          // global read position; local = e - nBase
+            float y = src_dot(&sig[e - nBase], &rows[(size_t)ph * kSrcRowC]);
+            if (k < cap) out[k] = y;
+            const float a = fabsf(y);
+            if (a > mx) mx = a;
+        }
+    }
+    *nout = (uint32_t)total;
+    *maxv = mx;
+    return TRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The small-batch formulation (gnuspeech_amd/csrc/trm_quad.h): four time slots per voice in the
 // feed-forward stages (closed-form tracks, oscillator phase as a prefix sum, direct-form FIR) and the
 // tube split over four parts.  Same interface as above.

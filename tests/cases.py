@@ -137,6 +137,20 @@ def golden_cases():
     return cases
 
 
+def corner_cases():
+    """name -> (params dict, frames): corners no reference fixture covers, checked against the (pinned) oracle.
+    pulse_no_rise_*: tp ~ 0 makes tableDiv1 = 0 -- the glottal table has no rise entries and is the fall alone
+    (TRMWavetable.m:81-96); narrow_band_20hz: a frication bandwidth far below Monet's 250 Hz minimum, where
+    alpha = (1/2 - beta)/2 (TRMFilters.m:16) cancels in fp32 -- pins the margin of the one-tangent band-pass form."""
+    out = {}
+    for tp in (0.0, 0.05):
+        p = tract_default_params(); p["tp"] = tp
+        out["pulse_no_rise_tp%g" % tp] = (p, static_frames(TRACT_VOWEL_FRAME, 21))
+    fr = static_frames([-12.0, 54.0, 6.0, 50.0, 5.4, 2500.0, 20.0, 0.8, 0.89, 0.99, 0.81, 0.76, 0.3, 1.23, 0.9, 0.1], 41)
+    out["narrow_band_20hz"] = (monet_default_params(44100.0), fr)
+    return out
+
+
 # ---------------------------------------------------------------- TRAcT's own loop (SURVEY 8f N4)
 def tract_shim_params():
     """shim/tract_tube.c's utterance-rate globals = Applications/TRAcT/tube.c:326-352 (what the program starts with)."""

@@ -101,6 +101,13 @@ def _batch_vs_oracle(g, pd, voices, tol=RMS_TOL):
     return worst
 
 
+@pytest.mark.parametrize("name", ["pulse_no_rise_tp0", "pulse_no_rise_tp0.05", "narrow_band_20hz"])
+def test_corner_cases(g, form, name):
+    """tests/cases.py corner_cases (a pulse without a rise, tp ~ 0; a 20 Hz frication band) in every kernel form."""
+    pd, frames = cases.corner_cases()[name]
+    _batch_vs_oracle(g, pd, [frames, frames[:7].copy()])
+
+
 def test_batch_static_vowels_config2(g, form):
     """BASELINE config 2 shape at a size the oracle finishes in seconds: 96 voices x 0.2 s."""
     fr = cases.config2_frames(96, nframes=51)

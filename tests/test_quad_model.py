@@ -68,6 +68,27 @@ def test_both_formulations_against_oracle(emul, name):
         assert abs(m.value - o["maximumSampleValue"]) / o["maximumSampleValue"] < 2e-4
 
 
+@pytest.mark.parametrize("name", ["pulse_no_rise_tp0", "pulse_no_rise_tp0.05", "narrow_band_20hz"])
+def test_corner_cases_against_oracle(emul, name):
+    """tests/cases.py corner_cases: a glottal pulse without a rise (tp ~ 0: tableDiv1 == 0, ADVICE r03 -- the select-free
+    table returned silence there) and a 20 Hz frication band, device arithmetic on the host against the oracle."""
+    import cases
+    pd, frames = cases.corner_cases()[name]
+    p = O.InputParams.from_dict(pd)
+    fr = np.ascontiguousarray(frames, dtype=np.float32)
+    o = O.synthesize(p, fr.astype(np.float64))
+    assert o["maximumSampleValue"] > 1e-4
+    for fn in (emul.trm_emul_synthesize, emul.trm_emul_synthesize_quad):
+        cap = len(fr) * 700 + 2000
+        out = np.zeros(cap, dtype=np.float32)
+        n, m = C.c_uint32(), C.c_float()
+        assert fn(C.byref(p), fr.ctypes.data_as(C.POINTER(C.c_float)), len(fr), out.ctypes.data_as(C.POINTER(C.c_float)), cap,
+                  C.byref(n), C.byref(m), None) == 0
+        assert n.value == o["numberSamples"]
+        e = (out[:n.value].astype(np.float64) - o["samples"]) / o["maximumSampleValue"]
+        assert float(np.sqrt(np.mean(e * e))) <= 1e-5, float(np.sqrt(np.mean(e * e)))
+
+
 @pytest.mark.parametrize("name", golden_io.TRACT_CASE_NAMES)
 def test_tract_order_arithmetic_against_the_reference(emul, name):
     """The device arithmetic in TRAcT's loop order (TRM_STREAM_MODE_TRACT: held parameters that step, x10 frication

@@ -22,8 +22,10 @@ def main():
         rows = [r for r in csv.DictReader(open(f)) if "trm_tube_kernel" in r["Kernel_Name"]]
         if rows:
             r = rows[-1]
-            lines.append("== last trm_tube_kernel dispatch: grid %s wg %s VGPR %s SGPR %s LDS %s scratch %s" % (
-                r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("VGPR_Count"), r.get("SGPR_Count"),
+            # rocprofv3 writes the geometry per dimension (Grid_Size_X = threads, not workgroups)
+            gx, wx = int(r.get("Grid_Size_X", 0)), int(r.get("Workgroup_Size_X", 0) or 1)
+            lines.append("== last trm_tube_kernel dispatch (%s): grid %d threads = %d workgroups of %d, VGPR %s SGPR %s LDS %s scratch %s" % (
+                r["Kernel_Name"].split("(")[0][-40:], gx, gx // wx, wx, r.get("VGPR_Count"), r.get("SGPR_Count"),
                 r.get("LDS_Block_Size"), r.get("Scratch_Size")))
             d = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows]
             lines.append("   dispatch durations ns: n=%d min=%d median=%d max=%d" % (len(d), min(d), sorted(d)[len(d) // 2], max(d)))
