@@ -11,8 +11,15 @@ A "step" = one pass of -[TRMTubeModel synthesize] over one resident batch of syn
                       environment), this process starts them as a CHILD `python -m torch.distributed.run` before it
                       touches the GPU and relays rank 0's line.
   --config K          the per-GPU workload by BASELINE.json configs[] index, whatever --gpus says: 1 = 4096 static
-                      tubes, 2 = 4096 time-varying tubes, 4 = ONE GPU's shard of configs[4] (8192 time-varying voices).
-                      `--gpus 1 --config 4` is the single-GPU run an N-rank line compares with (its `scaling_baseline`).
+                      tubes, 2 = 4096 time-varying tubes, 3 = the GnuTTSServer sentence batch (1024 ragged utterances of
+                      0.6 - 6 s, seed 20250119; `value` = the batch resident on the device, `end_to_end` = the same batch
+                      through the C-ABI host entry: H2D + kernels + D2H, fp32 and int16), 4 = ONE GPU's shard of
+                      configs[4] (8192 time-varying voices).  `--gpus 1 --config 4` is the single-GPU run an N-rank line
+                      compares with (its `scaling_baseline`).
+
+The default line (N = 1, configs[1]) also carries a `stream` record: 1 048 576 voices streamed in ten 100 ms chunks through
+trm_stream_push_device (the metric's "concurrent real-time voices" half: every chunk must beat its audio time); --no-stream
+leaves it out.
 
 The N-rank line is self-contained for weak scaling: besides the contract's MAX-over-ranks time it carries every rank's
 own elapsed and kernel time (`per_rank_ms`, `per_rank_kernel_ms`, gathered after the timed region), `per_gpu_value`, and
@@ -62,6 +69,55 @@ def usable_cores():
         except (OSError, ValueError):
             pass
     return n
+
+
+def cpu_baseline_ragged(pd, voices, wall_s=3.0):
+    """cpu_baseline() for a ragged batch (configs[3]): one oracle call per voice (the voices differ in length), every thread
+    works through its own share of the batch's voices, cyclically, until about `wall_s` seconds have passed."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import oracle_lib as O
+    L = O.lib()
+    cores = usable_cores()
+    op = O.InputParams.from_dict(pd)
+    arrs = [np.ascontiguousarray(np.asarray(v, dtype=np.float32).astype(np.float64)) for v in voices]
+
+    def run(i):
+        n = C.c_uint64()
+        a = arrs[i % len(arrs)]
+        rc = L.trm_oracle_run_voices(C.byref(op), a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0], 1, 0, 1, C.byref(n))
+        assert rc == 0, rc
+        return n.value
+    res, cnt = [0] * cores, [0] * cores
+    go = threading.Barrier(cores + 1)
+    stop = [0.0]
+
+    def worker(t):
+        go.wait()
+        i = t
+        while time.perf_counter() < stop[0]:
+            res[t] += run(i)
+            cnt[t] += 1
+            i += cores
+        go.wait()
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+    for t in th:
+        t.start()
+    stop[0] = time.perf_counter() + wall_s
+    go.wait()
+    t0 = time.perf_counter()
+    go.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    return {"value": float(sum(res)) / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "per_core": float(sum(res)) / dt / cores, "host_hardware_threads": os.cpu_count(),
+            "sample": "%d voice runs (the batch's %d utterances of %d - %d frames, every thread its own share, cyclically) = %.0f s of CPU "
+                      "work in %.2f s on %d threads (the cores this job may use: %d of the host's %d hardware threads), "
+                      "oracle/trm_oracle.c (double), one voice per task"
+                      % (sum(cnt), len(arrs), min(len(a) for a in arrs), max(len(a) for a in arrs), dt * cores, dt, cores, cores,
+                         os.cpu_count() or cores)}
 
 
 def cpu_baseline(pd, frames, wall_s=3.0):
@@ -120,34 +176,43 @@ def cpu_baseline(pd, frames, wall_s=3.0):
                       % (cores * per_thread, nv, per_voice_samples, dt * cores, dt, cores, cores, os.cpu_count() or cores)}
 
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")
-CONFIGS = {1: (4096, "static"), 2: (4096, "timevarying"), 4: (8192, "timevarying")}     # BASELINE.json configs[K] per GPU
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r04.json")
+# BASELINE.json configs[K] per GPU: (voices, kind)
+CONFIGS = {1: (4096, "static"), 2: (4096, "timevarying"), 3: (1024, "ragged"), 4: (8192, "timevarying")}
+# What a wave64 VALU instruction of each kernel costs a SIMD that several waves share, weighted by the kernel's static
+# instruction mix (tools/isa_mix.py: plain VGPR-operand fp32 / integer instructions 2.4 cycles; packed, fp64, DPP,
+# compare / select and scalar-operand ones 4.3; transcendentals 8.2 -- tools/ubench/valu_ceiling.hip).  Round 4 put the
+# microbenchmark under the counters (profiles/valu_pmc_calibration_r04.txt): SQ_ACTIVE_INST_VALU charges ONE quad-cycle per
+# instruction of any class (two per transcendental), i.e. it counts instructions, not busy SIMD cycles -- round 3's
+# "4 x SQ_ACTIVE_INST_VALU = the launch's SIMD cycles: the VALUs never idle" is withdrawn and these class prices are back.
+ISSUE_CYCLES = {"oct": 3.32, "quad": 3.45, "wide": 3.10, "wide/split": 3.22}
 
 
 def lookup_traffic(voices, nframes, kind, form, avg_launch_s):
     """HBM bytes and VALU instructions per launch come from separate rocprofv3 --pmc passes (they cannot be combined
-    with the timed run).  profiles/traffic_r03.json holds one entry per (workload, kernel form) that was profiled
+    with the timed run).  profiles/traffic_r04.json holds one entry per (workload, kernel form) that was profiled
     (tools/profile_workload.sh + tools/make_traffic.py), the whole file stamped with kernel_source_hash(): an entry is
     only quoted for THIS workload in THIS kernel form built from THESE kernel sources; otherwise traffic is null."""
     try:
         tj = json.load(open(TRAFFIC_FILE))
     except (OSError, ValueError):
-        return None, None, "no PMC profile (profiles/traffic_r03.json missing)"
+        return None, None, "no PMC profile (profiles/%s missing)" % os.path.basename(TRAFFIC_FILE)
     if tj.get("kernel_source_sha16") != kernel_source_hash():
-        return None, None, "profiles/traffic_r03.json is stale (kernel sources changed since the PMC passes): not quoted"
+        return None, None, "profiles/%s is stale (kernel sources changed since the PMC passes): not quoted" % os.path.basename(TRAFFIC_FILE)
     for e in tj.get("entries", []):
         w = e.get("workload", {})
         if (w.get("voices_per_gpu"), w.get("frames_per_voice"), w.get("kind"), w.get("kernel_form")) != (voices, nframes, kind, form):
             continue
         valu = None
         if e.get("SQ_INSTS_VALU") and e.get("issue_cycles_per_valu"):
-            # wave64 VALU instructions of one launch (PMC) x the mix-weighted issue cost measured by tools/ubench
-            # against this run's launch time on 1024 SIMDs at the 2.4 GHz peak clock
+            # wave64 VALU instructions of one launch (PMC) x the mix-weighted issue cost of the kernel's instruction classes
+            # (ISSUE_CYCLES above) against this run's launch time on 1024 SIMDs at the 2.4 GHz peak clock
             valu = {"insts_per_launch": e["SQ_INSTS_VALU"], "issue_cycles_per_inst": e["issue_cycles_per_valu"],
                     "source": e["source"] + "; " + e.get("issue_cycles_source", ""),
-                    "frac_of_issue_slots": e["SQ_INSTS_VALU"] * e["issue_cycles_per_valu"] / (avg_launch_s * 2.4e9 * 1024)}
+                    "frac_of_issue_slots": e["SQ_INSTS_VALU"] * e["issue_cycles_per_valu"] / (avg_launch_s * 2.4e9 * 1024),
+                    "wait_any_over_wave_cycles": e.get("SQ_WAIT_ANY_over_WAVE_CYCLES")}
         return e["traffic_bytes_per_launch"], valu, e["source"]
-    return None, None, "no PMC profile for this workload / kernel form in profiles/traffic_r03.json"
+    return None, None, "no PMC profile for this workload / kernel form in profiles/%s" % os.path.basename(TRAFFIC_FILE)
 
 
 def resolve_workload(a, world):
@@ -168,9 +233,11 @@ def parse_args(argv=None):
                     help="per-GPU workload = BASELINE.json configs[K] (4: one GPU's shard of it); default 1 at --gpus 1, 4 at --gpus N")
     ap.add_argument("--voices", type=int, default=None, help="voices per GPU (overrides --config's)")
     ap.add_argument("--seconds", type=float, default=1.0)
-    ap.add_argument("--workload", default=None, choices=["static", "timevarying"],
-                    help="overrides --config's: static (config-2 voices) or timevarying (config-3 voices)")
+    ap.add_argument("--workload", default=None, choices=["static", "timevarying", "ragged"],
+                    help="overrides --config's: static (config-2 voices), timevarying (config-3 voices) or ragged (configs[3]'s utterances)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="leave the default line's `stream` record out")
+    ap.add_argument("--split", default="auto", help="time split (include/trm_c_api.h): auto | off | control periods per segment")
     ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
                     help="stream: the metric's second half demonstrated -- --voices N (default 1048576) streamed in 100 ms chunks "
                          "through trm_stream_push_device for --seconds (default 2) of audio, PCM left on the device; a step = one chunk")
@@ -199,6 +266,47 @@ def stream_mode(a, rank, world):
            "config": {"workload": "%d time-varying voices streamed in 100 ms chunks (25 control frames) for %g s of audio through "
                                   "trm_stream_push_device; frames and fp32 PCM resident on the device" % (N, seconds), "mode": "stream"}}
     print(json.dumps(out), flush=True)
+
+
+def stream_record(N=1048576, chunks=10, chunk_frames=25):
+    """The metric's second half on the default line: N voices streamed in `chunks` chunks of 100 ms (25 control frames) through
+    trm_stream_push_device, frames and fp32 PCM resident on the device, every chunk waited for on its own."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import torch
+    import realtime_voices as rv
+    try:
+        r = rv.run(N, chunks * chunk_frames / 250.0, chunk_frames, False)
+    except Exception as e:          # (a smaller device: report, do not lose the line)
+        return {"voices": N, "error": str(e)[:200]}
+    finally:
+        torch.cuda.empty_cache()
+    return {"voices": N, "chunks": r["chunks"], "chunk_ms_audio": r["chunk_ms_audio"], "chunk_ms_median": r["median_ms"],
+            "chunk_ms_max": r["max_ms"], "held_real_time": r["held"], "samples_per_s": N * 4410 / (r["median_ms"] * 1e-3),
+            "how": "trm_stream_push_device, 25 control frames per push, frames and fp32 PCM on the device, one synchronisation per chunk "
+                   "(tools/realtime_voices.py)"}
+
+
+def end_to_end_record(g, pd, caller_order, reps=3):
+    """configs[3] as SURVEY 8(d) defines "end to end through TRM": the C-ABI host entry -- H2D of the frames, the kernels, the
+    converter, per-voice maxima, D2H of the PCM -- on the batch in the CALLER's order (the library sorts by length itself),
+    into an output buffer the caller keeps between calls; fp32 PCM and the containers' int16."""
+    import numpy as np
+    b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    out = {}
+    for name, fn in (("fp32", b.synthesize), ("int16", b.synthesize_int16)):
+        fn(caller_order, reuse_output=True)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            pcm, ns, mx = fn(caller_order, reuse_output=True)
+            ts.append(time.perf_counter() - t0)
+        total = int(np.asarray(ns, dtype=np.int64).sum())
+        out[name] = {"ms": min(ts) * 1e3, "samples_per_s": total / min(ts), "output_samples": total}
+        pcm = None
+    out["time_split"] = list(b.last_time_split)
+    out["how"] = ("trm_batch_synthesize_host / _host_int16 through gnuspeech_amd.TRMBatch (packing the 1024 per-voice arrays + H2D + kernels + "
+                  "D2H into a kept buffer), best of %d" % reps)
+    return out
 
 
 def main():
@@ -230,8 +338,16 @@ def main():
     import cases
     pd = cases.monet_default_params(44100.0)
     nframes = int(round(a.seconds * 250)) + 1
+    caller_order = None
     # per-rank shard: independent voices, different seed offset per rank (no data-path collective)
-    if workload == "static":
+    if workload == "ragged":
+        caller_order = cases.config4_frames(voices, seed=20250119 + rank)
+        frames = sorted(caller_order, key=len, reverse=True)           # resident batch: longest first (gnuspeech_amd/shard.py's order)
+        nframes = max(len(u) for u in frames)
+        wname = ("configs[3]: GnuTTSServer sentence batch, %d ragged utterances of %.1f - %.1f s (%.0f s of speech, seed 20250119) @ 44.1 kHz, "
+                 "resident on the device, longest first" % (voices, min(len(u) for u in frames) / 250.0, nframes / 250.0,
+                                                            sum(len(u) - 1 for u in frames) / 250.0))
+    elif workload == "static":
         frames = cases.config2_frames(voices, nframes=nframes, seed=20250117 + rank)
         wname = "configs[1]: batch=%d static-vowel tubes x %.3g s @ 44.1 kHz, Monet default voice, fp32" % (voices, a.seconds)
     else:
@@ -245,7 +361,7 @@ def main():
     # the CPU leg first: before this process has a GPU context (rank 0 at N=1 only)
     cpu = None
     if rank == 0 and not dist and not a.no_cpu_baseline:
-        cpu = cpu_baseline(pd, frames)
+        cpu = cpu_baseline_ragged(pd, frames) if workload == "ragged" else cpu_baseline(pd, frames)
 
     import torch
     import gnuspeech_amd as g
@@ -264,6 +380,7 @@ def main():
 
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd), device=local_rank)
     b.set_kernel(a.kernel)
+    b.set_time_split(a.split if a.split in ("auto", "off") else int(a.split))
     st = b.prepare_device(frames, device="cuda:%d" % local_rank)
     stream = torch.cuda.current_stream()
 
@@ -314,10 +431,15 @@ def main():
     value = total_samples / dt
     # roofline of the dominant kernel (trm_tube_kernel*): algorithmic bytes per launch =
     # 4 B x output samples + 64 B x frames, / its average launch duration
-    alg_bytes = 4.0 * samples_per_step_rank + 64.0 * voices * nframes
+    frames_total = int(np.asarray(st["nframes_host"]).sum())
+    alg_bytes = 4.0 * samples_per_step_rank + 64.0 * frames_total
     avg_launch_s = (kern_ms / max(1, launches)) * 1e-3
     achieved = alg_bytes / avg_launch_s / 1e9
-    traffic, valu, traffic_note = lookup_traffic(voices, nframes, workload, b.last_kernel, avg_launch_s)
+    split = b.last_time_split
+    form = b.last_kernel + ("/split" if split[0] else "")
+    traffic, valu, traffic_note = lookup_traffic(voices, nframes, workload, form, avg_launch_s)
+    kernel_name = {"wide": "trm_tube_kernel<0>", "quad": "trm_tube_kernel_q", "oct": "trm_tube_kernel_o",
+                   "wide/split": "trm_tube_kernel<2> (+ trm_phase_kernel)"}[form]
     out = {
         "metric": "audio samples/s (whole node) + concurrent real-time tube voices",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -327,14 +449,27 @@ def main():
         "config": {"workload": wname, "voices_per_gpu": voices, "frames_per_voice": nframes,
                    "output_samples_per_voice": samples_per_step_rank // max(1, voices),
                    "tube_rate_hz": b.derived["sampleRate"], "control_rate_hz": 250, "sharding": "voices, no collective",
-                   "kernel_form": b.last_kernel},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": {"wide": "trm_tube_kernel", "quad": "trm_tube_kernel_q", "oct": "trm_tube_kernel_o"}[b.last_kernel], "avg_launch_ms": kern_ms / max(1, launches),
+                   "kernel_form": form,
+                   "time_split": ({"segment_periods": split[0], "warmup_periods": split[1]} if split[0] else None)},
+        # what binds is VALU issue (a scalar recurrence: ~3.6 wave64 instructions per output sample and lane against 4.36
+        # algorithmic bytes); the HBM fraction north_star asks for is `frac` (= `hbm_frac`), priced as the contract says
+        "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": kernel_name, "avg_launch_ms": kern_ms / max(1, launches),
                      "algorithmic_bytes_per_launch": alg_bytes, "valu_issue": valu,
-                     "note": "VALU-issue bound scalar recurrence (SURVEY 8d); HBM-write fraction reported as BASELINE asks"},
+                     "issue_cycles_per_inst_by_class_mix": ISSUE_CYCLES[form],
+                     "note": "achieved / peak / frac are the HBM figures BASELINE asks for (algorithmic bytes / device time of a launch, "
+                             "hipEvents); the kernel is VALU-issue bound (SURVEY 8d): valu_issue.frac_of_issue_slots = PMC instruction "
+                             "count x the class-mix issue cost / (launch time x 1024 SIMDs x 2.4 GHz)"},
         "cpu_baseline": cpu,
     }
+    if rank == 0 and not dist and workload == "ragged":
+        out["end_to_end"] = end_to_end_record(g, pd, caller_order)
+    if rank == 0 and not dist and config == 1 and a.voices is None and a.workload is None and not a.no_stream:
+        del st, b
+        torch.cuda.empty_cache()
+        out["stream"] = stream_record()
     if dist:
         out["per_rank_ms"] = per_rank_ms                   # ms per step, every rank's own clock (launches + device sync)
         out["per_rank_kernel_ms"] = per_rank_kernel_ms     # average tube-kernel launch per rank (hipEvents)

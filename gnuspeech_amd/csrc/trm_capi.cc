@@ -110,6 +110,7 @@ struct trm_batch {
     uint32_t lastSplitPeriods = 0, lastSplitWarm = 0;      // what the last launch did (0: whole utterances)
     DevBuf<double> dSegPhase;
     uint32_t *dGate = nullptr;
+    uint64_t hintTotalPeriods = 0;       // set by the host-buffer entries (they see every voice's length) for the launch that follows
 };
 
 struct trm_tube {
@@ -429,23 +430,19 @@ static uint32_t split_warm_samples(const trm::Const &c)
     return (uint32_t)ceil(w) + 64u;
 }
 
-// predicted launch time, ms per second of speech at Monet's rates (19 750 tube samples): the measured figures of the
-// kernel forms on 256 CUs (profiles/sweep_forms_r03.txt), scaled by the occupancy of the device at hand
+// Predicted launch time in ms per second of speech at Monet's rates (19 750 tube samples), from the measured figures of the
+// kernel forms on 256 CUs (profiles/sweep_forms_r04.txt, split_probe_r04.txt), by workgroups per CU.
 static double unsplit_cost(const trm_batch *b, size_t nvoices, int which)
 {
     const double cus = b->cus > 0 ? b->cus : 256, vpc = (double)nvoices / cus;
     if (which == TRM_KERNEL_OCT) return vpc <= 4 ? 2.06 : vpc <= 8 ? 2.24 : 2.37 * (vpc <= 16 ? 1.0 : vpc / 16.0);
-    if (which == TRM_KERNEL_QUAD) return vpc <= 16 ? 3.1 : vpc <= 32 ? 4.0 : 4.0 * vpc / 32.0;
+    if (which == TRM_KERNEL_QUAD) return vpc <= 16 ? 3.1 : vpc <= 32 ? 4.1 : 4.1 * vpc / 32.0;
     return vpc <= 64 ? 6.5 : vpc <= 128 ? 7.8 : 7.8 * vpc / 128.0;
 }
-static double split_cost(const trm_batch *b, uint64_t workgroups)
-{
-    const double cus = b->cus > 0 ? b->cus : 256, w = (double)workgroups / cus;
-    return w <= 1 ? 6.5 : w <= 2 ? 6.5 + 1.3 * (w - 1) : 7.8 * w / 2;
-}
 
-// `which` = the kernel form the launch would take unsplit
-static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, SplitPlan &pl)
+// `which` = the kernel form the launch would take unsplit.  `totalPeriods` = the control periods of all voices together where
+// the caller knows them (the host-buffer entries; 0: every voice is taken to be as long as the longest).
+static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, uint64_t totalPeriods, SplitPlan &pl)
 {
     pl = SplitPlan();
     const int setting = b->splitSetting;
@@ -460,14 +457,35 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
     uint32_t periods = 0;
     if (setting > 0) periods = (uint32_t)setting;
     else {
-        // AUTO: the segment length with the shortest predicted launch, taken when it beats whole utterances by a margin
-        const double whole = unsplit_cost(b, nvoices, which) * P;
-        double best = whole * 0.85;
-        const uint64_t wgPerSeg = (nvoices + 63) / 64;
-        for (uint32_t nseg = 2; nseg <= 512 && nseg <= P; nseg++) {
-            const uint32_t sp = (P + nseg - 1) / nseg;
-            if ((uint64_t)sp * CP < 512) break;                          // (segments of a few hundred samples: all warm-up)
-            const double t = split_cost(b, wgPerSeg * ((P + sp - 1) / sp)) * (sp + warm) * 1.03 + 0.03 * 19750.0 / CP;
+        // AUTO.  A time-split launch pays when its workgroups -- one per segment and block of 64 voices -- find room on the
+        // chip at once: the one-voice-per-lane kernel runs one workgroup per CU at 6.6 and two at 7.9 ms per second of
+        // speech, and a launch that needs a second round of workgroups loses what the split gained (measured:
+        // profiles/split_probe_r04.txt).  So: the two segment counts that fill one resp. two workgroups per CU, the
+        // shorter predicted launch of the two, taken when it beats whole utterances by a tenth.
+        const double cus = b->cus > 0 ? b->cus : 256;
+        const double whole = unsplit_cost(b, nvoices, which) * P * CP / 19750.0;
+        double best = whole * 0.9;
+        // (segments of at least half a warm-up: a launch never does more than three times the arithmetic of whole
+        // utterances -- shorter ones still shorten a nearly empty chip's launch a little, at ten times the work)
+        uint32_t minPeriods = (255u + CP) / CP > 4u ? (255u + CP) / CP : 4u;
+        minPeriods = minPeriods > (warm + 1) / 2 ? minPeriods : (warm + 1) / 2;
+        for (int perCu = 1; perCu <= 2; perCu++) {
+            // workgroups of a launch cut every sp periods: per segment the blocks of 64 voices that reach it
+            auto workgroups = [&](uint32_t sp) -> uint64_t {
+                const uint64_t nseg = (P + sp - 1) / sp;
+                if (totalPeriods == 0) return nseg * ((nvoices + 63) / 64);
+                return (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (nseg + 1) / 2;      // (+ the segments' partly filled last blocks)
+            };
+            // the shortest segment whose launch still fits perCu workgroups per CU
+            uint32_t lo = minPeriods, hi = P;
+            if (workgroups(hi) > (uint64_t)(perCu * cus)) continue;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) / 2;
+                if (workgroups(mid) <= (uint64_t)(perCu * cus)) hi = mid; else lo = mid + 1;
+            }
+            const uint32_t sp = lo;
+            if (sp >= P) continue;
+            const double t = 0.08 + (perCu == 1 ? 6.6 : 7.9) * (double)(sp + warm) * CP / 19750.0 * 1.04;
             if (t < best) { best = t; periods = sp; }
         }
     }
@@ -598,7 +616,8 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // the caller asked for by name is run as asked (whole utterances) unless the split was asked for by name too.
     SplitPlan pl;
     const bool formByName = b->kernel != TRM_KERNEL_AUTO || b->envKernel != TRM_KERNEL_AUTO;
-    if (!(formByName && b->splitSetting <= 0) && (rc = plan_time_split(b, nvoices, max_nframes, which, pl))) return rc;
+    if (!(formByName && b->splitSetting <= 0) && (rc = plan_time_split(b, nvoices, max_nframes, which, b->hintTotalPeriods, pl))) return rc;
+    b->hintTotalPeriods = 0;                          // (a hint holds for one launch)
     b->lastSplitPeriods = pl.periods;
     b->lastSplitWarm = pl.periods ? pl.warm : 0;
     if (pl.periods) {
@@ -1108,6 +1127,15 @@ static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frame
     HIP_TRY(hipMemcpyAsync(b->dFrameOff.p, permuted ? pFrameOff.data() : frame_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->dOutOff.p, permuted ? pOutOff.data() : out_offset, nvoices * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(b->dNFrames.p, permuted ? pNFrames.data() : nframes, nvoices * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    {
+        // what the time-split planner may know about a ragged batch: its control periods in all (the kernels' voice index
+        // runs from the longest voice down: the segments' workgroups fill up front to back)
+        uint64_t tp = 0;
+        for (size_t v = 0; v < nvoices; v++) tp += nframes[v] > 1 ? nframes[v] - 1 : 0;
+        bool desc = true;
+        for (size_t v = 1; v < nvoices && desc && !permuted; v++) desc = nframes[v] <= nframes[v - 1];
+        b->hintTotalPeriods = (permuted || desc) ? tp : 0;
+    }
     rc = trm_batch_synthesize_device(b, nvoices, b->dFrames.p, b->dFrameOff.p, b->dNFrames.p, maxFrames, b->dOut.p,
                                      b->dOutOff.p, b->dNSamples.p, b->dMax.p, s);
     if (rc) return rc;

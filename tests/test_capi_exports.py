@@ -159,7 +159,7 @@ def test_bench_refuses_a_world_size_that_is_not_gpus(tmp_path):
 
 
 def test_bench_traffic_file_is_stamped_with_the_kernel_sources(tmp_path, monkeypatch):
-    """profiles/traffic_r03.json (what bench.py quotes roofline.traffic / valu_issue from) is a LIST of PMC results keyed by
+    """profiles/traffic_r04.json (what bench.py quotes roofline.traffic / valu_issue from) is a LIST of PMC results keyed by
     workload and kernel form, stamped as a whole with the hash of the kernel sources it was measured on: a stale file is
     refused, an entry is quoted only for its own workload in its own kernel form."""
     import json, sys
@@ -181,13 +181,13 @@ def test_bench_traffic_file_is_stamped_with_the_kernel_sources(tmp_path, monkeyp
     assert bench.lookup_traffic(65536, 251, "static", "oct", 1e-3)[0] is None             # another kernel form
     assert bench.lookup_traffic(4096, 251, "static", "wide", 1e-3)[0] is None             # another batch
     # the committed file, where there is one, has this shape
-    committed = os.path.join(ROOT, "profiles", "traffic_r03.json")
+    committed = os.path.join(ROOT, "profiles", "traffic_r04.json")
     if os.path.exists(committed):
         tj = json.load(open(committed))
         assert set(("kernel_source_sha16", "entries")) <= set(tj) and len(tj["entries"]) >= 1
         for e in tj["entries"]:
             assert set(("workload", "traffic_bytes_per_launch", "SQ_INSTS_VALU", "issue_cycles_per_valu", "source")) <= set(e)
-            assert e["workload"]["kernel_form"] in ("oct", "quad", "wide")
+            assert e["workload"]["kernel_form"] in ("oct", "quad", "wide", "wide/split")
 
 
 def test_bench_config_flag_names_the_per_gpu_workload():
@@ -202,6 +202,8 @@ def test_bench_config_flag_names_the_per_gpu_workload():
     assert bench.resolve_workload(bench.parse_args(["--gpus", "1", "--config", "4"]), 1) == (4, 8192, "timevarying")
     assert bench.resolve_workload(bench.parse_args(["--gpus", "2", "--config", "1"]), 2) == (1, 4096, "static")
     assert bench.resolve_workload(bench.parse_args(["--config", "2"]), 1) == (2, 4096, "timevarying")
+    assert bench.resolve_workload(bench.parse_args(["--config", "3"]), 1) == (3, 1024, "ragged")      # the GnuTTSServer sentence batch
+    assert bench.parse_args([]).split == "auto" and not bench.parse_args([]).no_stream
     assert bench.resolve_workload(bench.parse_args(["--voices", "65536", "--kernel", "wide"]), 1) == (1, 65536, "static")
     assert bench.parse_args([]).steps == 200          # half a second of GPU work: the driver's sampler sees the run
     assert bench.parse_args([]).mode == "batch" and bench.parse_args(["--mode", "stream", "--voices", "2097152"]).mode == "stream"

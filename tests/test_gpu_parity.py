@@ -897,20 +897,27 @@ def test_host_entry_leaves_gaps_between_voices_alone(g, form):
 
 
 
-def test_full_size_configs4_per_gpu_batch(g):
-    """BASELINE configs[4]'s per-GPU shard at FULL size: 8192 config-3 voices (time-varying gnuspeech.input tracks) x 1 s, the
-    batch that runs as two co-resident workgroups per CU.  Size-independent properties (exact counts, finite, the reported
-    maximum is the maximum, identical tracks give identical bits wherever they sit) and a sample of voices against the oracle."""
+@pytest.mark.parametrize("split", ["auto", "off"])
+def test_full_size_configs4_per_gpu_batch(g, split):
+    """BASELINE configs[4]'s per-GPU shard at FULL size: 8192 config-3 voices (time-varying gnuspeech.input tracks) x 1 s, as
+    AUTO runs it since round 4 -- cut in time, four segments of 64 voices per workgroup, two workgroups on every CU -- and as
+    whole utterances (the four-lane form, two co-resident workgroups per CU).  Size-independent properties (exact counts,
+    finite, the reported maximum is the maximum, identical tracks give identical bits wherever they sit) and a sample of
+    voices against the oracle."""
     import torch
     pd = cases.monet_default_params(44100.0)
     fr = cases.config3_frames(8192, nframes=251)
     fr[8191] = fr[5]
     fr[4100] = fr[5]
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    b.set_time_split(split)
     st = b.prepare_device(fr)
     b.synthesize_device(st)
     torch.cuda.synchronize()
-    assert b.last_kernel == "quad"
+    if split == "auto":
+        assert b.last_kernel == "wide" and b.last_time_split == (63, 36)
+    else:
+        assert b.last_kernel == "quad" and b.last_time_split == (0, 0)
     ns = st["number_samples"].cpu().numpy()
     assert np.all(ns == 44159)
     out = st["out"].cpu().numpy().reshape(8192, st["out_alloc"] // 8192)[:, :44159]

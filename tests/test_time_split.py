@@ -121,7 +121,8 @@ def test_split_launch_matches_reference_fixture(g, name, seg):
     b = _batch(g, gold["params_dict"], seg)
     pcm, ns, mx = b.synthesize([gold["frames"], gold["frames"][:seg + 3].copy(), gold["frames"][:2].copy()])
     nper = len(gold["frames"]) - 1
-    assert b.last_time_split[0] == (seg if seg < nper else 0) and b.last_kernel == "wide"
+    assert b.last_time_split[0] == (seg if seg < nper else 0)         # (a fixture of at most `seg` periods is one segment: whole)
+    assert b.last_kernel == ("wide" if seg < nper else "oct")
     assert int(ns[0]) == gold["numberSamples"]
     m = gold["maximumSampleValue"]
     assert nrms(pcm[0], gold["samples_f32"].astype(np.float64), m) <= RMS_TOL

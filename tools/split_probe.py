@@ -33,13 +33,17 @@ def timed(frames, label, settings, reps=5, kernel="auto"):
             label, sp, b.last_time_split, b.last_kernel, dt * 1e3, km / max(1, n), st["total_out"] / dt), flush=True)
 
 
-which = sys.argv[1:] or ["config3", "static", "tv"]
+AUTO_ONLY = "--auto" in sys.argv
+which = [x for x in sys.argv[1:] if not x.startswith("--")] or ["config3", "static", "tv"]
+if AUTO_ONLY:
+    _timed = timed
+    timed = lambda fr, label, settings, **k: _timed(fr, label, ["off", "auto"], **k)
 if "config3" in which:
     utt = cases.config4_frames(1024)
     utt.sort(key=len, reverse=True)
     timed(utt, "configs[3] 1024 ragged utterances", ["off", "auto", 140, 105, 70, 50, 35])
 if "static" in which:
-    for V in (1024, 4096, 8192, 12288, 16384):
+    for V in ((64, 256, 1024, 2048, 4096, 6144, 8192, 10240, 12288, 14336, 16384, 24576, 32768) if AUTO_ONLY else (1024, 4096, 8192, 12288, 16384)):
         fr = cases.config2_frames(V, nframes=251)
         timed(fr, "%d static vowels x 1 s" % V, ["off", "auto", 125, 84, 63, 50, 42, 32, 25])
 if "tv" in which:

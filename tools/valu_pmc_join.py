@@ -18,6 +18,8 @@ agg = collections.defaultdict(dict)
 order = []
 for f in glob.glob(pmc_dir + "/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
+        if "void k<" not in r["Kernel_Name"]:       # (the runtime's own copy kernels between the launches)
+            continue
         d = int(r["Dispatch_Id"])
         if d not in agg:
             order.append(d)
