@@ -237,6 +237,7 @@ def parse_args(argv=None):
                     help="overrides --config's: static (config-2 voices), timevarying (config-3 voices) or ragged (configs[3]'s utterances)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="leave the default line's `stream` record out")
+    ap.add_argument("--no-end-to-end", action="store_true", help="leave configs[3]'s `end_to_end` record out (profiling passes)")
     ap.add_argument("--split", default="auto", help="time split (include/trm_c_api.h): auto | off | control periods per segment")
     ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
                     help="stream: the metric's second half demonstrated -- --voices N (default 1048576) streamed in 100 ms chunks "
@@ -464,7 +465,7 @@ def main():
                              "count x the class-mix issue cost / (launch time x 1024 SIMDs x 2.4 GHz)"},
         "cpu_baseline": cpu,
     }
-    if rank == 0 and not dist and workload == "ragged":
+    if rank == 0 and not dist and workload == "ragged" and not a.no_end_to_end:
         out["end_to_end"] = end_to_end_record(g, pd, caller_order)
     if rank == 0 and not dist and config == 1 and a.voices is None and a.workload is None and not a.no_stream:
         del st, b

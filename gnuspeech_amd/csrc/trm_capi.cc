@@ -446,7 +446,7 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
 {
     pl = SplitPlan();
     const int setting = b->splitSetting;
-    if (setting == TRM_TIME_SPLIT_OFF || !b->c.upsample || max_nframes < 2) return TRM_OK;
+    if (setting == TRM_TIME_SPLIT_OFF || max_nframes < 2) return TRM_OK;
     const uint32_t CP = (uint32_t)b->c.controlPeriod, P = max_nframes - 1;
     const uint32_t ws = split_warm_samples(b->c);
     if (ws == 0) {

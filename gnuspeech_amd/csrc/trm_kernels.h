@@ -120,6 +120,7 @@ struct DownArgs {
     int stream;
     long long n_origin, n_hi;
     uint32_t k_base, k_end;
+    uint32_t ntiles = 0;          // tiled kernel: time tiles of the launch (set by launch_downsample)
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);

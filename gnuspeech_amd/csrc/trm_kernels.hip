@@ -32,6 +32,7 @@
 #undef TRM_PRIO_CVT_S
 #undef TRM_PRIO_TUBE_S
 #undef TRM_PRIO_OSC_S
+#undef TRM_EXP_DOWN
 #endif
 #ifndef TRM_ABL
 #define TRM_ABL 0    // diagnostic ablations of the convert stage; 0 in the product
@@ -426,7 +427,13 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             const uint32_t slot = (nBase + n + (kSrcWindow - 1)) & (kYRing - 1);
             ring[slot] = y;
             if (slot < (uint32_t)kYMirror) ring[slot + kYRing] = y;   // mirror: windows never wrap
-            if (tubeOut && laneValid && n < ntubeLane + (sLast ? 2u * (uint32_t)C.padSize : 0u)) tubeOut[n] = y;
+            if (kSeg) {
+                // a segment writes its own stretch of the voice's tube-rate row (global index nBase + n), not its warm-up's;
+                // the voice's last segment appends the flush
+                const uint32_t gn = nBase + n;
+                if (tubeOut && laneValid && gn >= seg * A.seg_periods * CP && n < ntubeLane + (segLast ? 2u * (uint32_t)C.padSize : 0u))
+                    tubeOut[gn] = y;
+            } else if (tubeOut && laneValid && n < ntubeLane + (sLast ? 2u * (uint32_t)C.padSize : 0u)) tubeOut[n] = y;
         };
         static_assert(kTB == 2, "the tube stage ping-pongs two wave sets per step");
         STAMP_DECL
@@ -715,79 +722,150 @@ __global__ __launch_bounds__(256) void trm_downsample_kernel(const Const C, cons
 // reference's two wing loops over them -- same products in the same order as trm_downsample_kernel (taps past a wing's
 // end multiply by 0).  The per-voice maximum is an atomic max on the float's bits (non-negative), max_sample zeroed by
 // the launcher.
-constexpr int kDownCols = 32, kDownVoices = 32, kDownPerThread = 4;      // 256 threads: 32 outputs x 8 voice groups x 4 voices each
+// Round 4 (measured by ablation, profiles/ab_r04.txt: the kernel is bound by its window loads and its stores, the products
+// are a fifth of it): a tile is 64 outputs x 32 voices -- a wave's lanes are 64 consecutive outputs, so a store instruction
+// writes 256 contiguous bytes of one voice and the windows overlap their neighbours' by less (1.46 x the samples instead of
+// 1.85 x) --, a thread runs one output of EIGHT voices, two taps at a time (one coefficient read feeds eight products), the
+// per-voice addresses and counts are fetched before the staging instead of in front of the stores, and the voice's output
+// count comes from trm_down_count_kernel (its closed form is four 64-bit divisions: evaluated per thread and voice it was
+// most of the kernel's instructions).  Same products in the same order as ever.
+constexpr int kDownCols = 64, kDownVoices = 32, kDownPerThread = 8;      // 256 threads: 64 outputs x 4 voice groups x 8 voices each
 __global__ __launch_bounds__(kDownCols *kDownVoices / kDownPerThread) void trm_downsample_rows_kernel(const Const C, const DownArgs D, uint32_t xlen)
 {
     extern __shared__ float sDown[];
-    const uint32_t T = D.lmax + D.rmax, rp = T | 1u;          // odd LDS pitch: the 32 rows land in 32 banks
-    float *const sRow = sDown;                                // [32][rp]
-    float *const sXw = sDown + kDownCols * rp;                // [32 voices][xlen]
-    __shared__ uint32_t sNt[kDownVoices];
-    __shared__ uint64_t sOff[kDownVoices];
+#if defined(TRM_EXP_DOWN) && TRM_EXP_DOWN == 4
+    return;
+#endif
+    const uint32_t T = D.lmax + D.rmax, rp = T | 1u;          // odd LDS pitch: a wave's 64 rows land in different banks
+    float *const sRow = sDown;                                // [kDownCols][rp]
+    float *const sXw = sDown + kDownCols * rp;                // [kDownVoices][xlen]
     constexpr uint32_t kGroups = kDownVoices / kDownPerThread;
     const uint32_t tid = threadIdx.x, o = tid & (kDownCols - 1), w = tid / kDownCols;      // w: voice group 0..7
     const uint32_t pad = (uint32_t)C.padSize, inc = C.timeRegisterIncrement, CP = (uint32_t)C.controlPeriod;
-    const uint32_t k0 = D.k_base + blockIdx.x * kDownCols, v0 = blockIdx.y * kDownVoices;
-    // tube samples nOrg <= n < nOrg + sNt[voice] sit at tube + sOff[voice] (one-shot: the voice's own samples from 0)
-    const int64_t nOrg = D.stream ? (int64_t)D.n_origin : 0;
-    if (tid < (uint32_t)kDownVoices) {
-        const uint32_t vv = v0 + tid;
-        const uint32_t nfr = vv < D.nvoices ? min(D.nframes[vv], D.max_nframes) : 0u;
-        sNt[tid] = D.stream ? (vv < D.nvoices ? (uint32_t)(D.n_hi - D.n_origin) : 0u) : (nfr > 0 ? (nfr - 1) * CP : 0u);
-        sOff[tid] = vv < D.nvoices ? D.tube_offset[vv] : 0ull;
+    // Workgroups are dealt to the 8 XCDs in turn (b and b + 8 share an L2): give every XCD a CONTIGUOUS run of a voice
+    // group's time tiles, so that a tile's window overlaps what its own L2 has just fetched and neighbouring PCM lines are
+    // written through one L2 (gridDim.x is a multiple of 8: launch_downsample; the surplus tiles return).
+    const uint32_t tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (tile >= D.ntiles) return;
+    const uint32_t k0 = D.k_base + tile * kDownCols, v0 = blockIdx.y * kDownVoices;
+    // this thread's voices: their PCM rows and output counts (requested now, used after the products)
+    float *outRow[kDownPerThread];
+    uint32_t noutOf[kDownPerThread];
+    for (int q = 0; q < kDownPerThread; q++) {
+        const uint32_t v = v0 + w + q * kGroups;
+        const bool ok = v < D.nvoices;
+        outRow[q] = D.out + (ok ? D.out_offset[v] : 0ull);
+        noutOf[q] = ok ? D.number_samples[v] + D.k_base : 0u;
     }
+    // tube samples nOrg <= n < nOrg + nt sit at tube + tube_offset[voice] (one-shot: the voice's own samples from 0)
+    const int64_t nOrg = D.stream ? (int64_t)D.n_origin : 0;
     // the block's rows: output k0 + r has phase ((k0 + r) * inc) & 0xFFFF; 8 threads per row
     for (uint32_t r = tid >> 3; r < (uint32_t)kDownCols; r += blockDim.x >> 3) {
         const float *src = D.rows + (size_t)src_phase(k0 + r, inc) * D.pitch;
+#if defined(TRM_EXP_DOWN) && TRM_EXP_DOWN == 3
+        for (uint32_t i = tid & 7u; i < T; i += 8) sRow[r * rp + i] = 0.5f;
+#else
         for (uint32_t i = tid & 7u; i < T; i += 8) sRow[r * rp + i] = src[i];
+#endif
     }
-    __syncthreads();
-    // every voice's window: tube samples nLo .. nLo + xlen - 1 (zeros outside the voice's own samples); 8 threads per voice
+    // (no barrier here: the windows are fetched in the same breath as the rows -- every thread reads its voice's offset and
+    // length itself instead of through LDS, which cost a memory round trip and a barrier in front of the window loads)
+    // every voice's window: tube samples nLo .. nLo + xlen - 1 (zeros outside the voice's own samples); 8 threads per voice.
+    // Positions fit 32 bits (utterances end below 2^31 tube samples: trm_capi.cc); past the voice's last sample + flush the
+    // converter's ring still holds the lap before (src_ring_sample: down-sampling's "extra lap").
     const int64_t nLo = (int64_t)src_position(k0, inc) - (int64_t)pad - (int64_t)(D.lmax - 1);
+    const int32_t nLo32 = (int32_t)(nLo - nOrg);
     for (uint32_t ww = tid >> 3; ww < (uint32_t)kDownVoices; ww += blockDim.x >> 3) {
-        const float *src = D.tube + sOff[ww];
-        const int64_t nt = (int64_t)sNt[ww];
+        const uint32_t vv = v0 + ww;
+        const bool okv = vv < D.nvoices;
+        const uint32_t nfrv = okv ? min(D.nframes[vv], D.max_nframes) : 0u;
+        const float *src = D.tube + (okv ? D.tube_offset[vv] : 0ull);
+        const int32_t nt = (int32_t)(D.stream ? (okv ? (uint32_t)(D.n_hi - D.n_origin) : 0u) : (nfrv > 0 ? (nfrv - 1) * CP : 0u));
+        const int32_t total = nt + 2 * (int32_t)pad;
         for (uint32_t i = tid & 7u; i < xlen; i += 8) {
-            int64_t n = nLo + (int64_t)i - nOrg;
-            if (!D.stream) n = src_ring_sample(n, nt + 2 * (int64_t)pad);      // (one-shot: nt = the voice's tube samples)
+            int32_t n = nLo32 + (int32_t)i;
+            if (!D.stream && n >= total) n -= (int32_t)kSrcRing * ((n - total) / (int32_t)kSrcRing + 1);      // (one-shot: nt = the voice's tube samples)
+#if defined(TRM_EXP_DOWN) && TRM_EXP_DOWN == 2
+            sXw[ww * xlen + i] = (n >= 0 && n < nt) ? 0.25f : 0.0f;
+#else
             sXw[ww * xlen + i] = (n >= 0 && n < nt) ? src[n] : 0.0f;
+#endif
         }
     }
     __syncthreads();
     const uint32_t k = k0 + o;
     const float *row = &sRow[o * rp];
     const uint32_t centre = (uint32_t)((int64_t)src_position(k, inc) - (int64_t)pad - nLo);       // tube sample e - pad in the window
-    // this thread's four voices: w, w + 8, w + 16, w + 24 of the tile; one coefficient read feeds four products
+    // this thread's voices: w, w + kGroups, ... of the tile; one coefficient read feeds a product of each
     float acc[kDownPerThread];
     const float *xw[kDownPerThread];
     for (int q = 0; q < kDownPerThread; q++) {
         acc[q] = 0.0f;
         xw[q] = &sXw[(w + q * kGroups) * xlen + centre];
     }
-    for (uint32_t j = 0; j < D.lmax; j++) {
-        const float c = row[j];
-        for (int q = 0; q < kDownPerThread; q++) acc[q] += xw[q][-(int)j] * c;
-    }
-    for (uint32_t j = 0; j < D.rmax; j++) {
-        const float c = row[D.lmax + j];
-        for (int q = 0; q < kDownPerThread; q++) acc[q] += xw[q][1 + j] * c;
+#if defined(TRM_EXP_DOWN) && TRM_EXP_DOWN == 1
+    for (int q = 0; q < kDownPerThread; q++) acc[q] = xw[q][0] * row[q];
+    if (false)
+#endif
+    {
+        uint32_t j = 0;
+        for (; j + 1 < D.lmax; j += 2) {
+            const float c0 = row[j], c1 = row[j + 1];
+            for (int q = 0; q < kDownPerThread; q++) {
+                const float x0 = xw[q][-(int)j], x1 = xw[q][-(int)j - 1];
+                acc[q] += x0 * c0;
+                acc[q] += x1 * c1;
+            }
+        }
+        if (j < D.lmax) {
+            const float c = row[j];
+            for (int q = 0; q < kDownPerThread; q++) acc[q] += xw[q][-(int)j] * c;
+        }
+        const float *rrow = row + D.lmax;
+        for (j = 0; j + 1 < D.rmax; j += 2) {
+            const float c0 = rrow[j], c1 = rrow[j + 1];
+            for (int q = 0; q < kDownPerThread; q++) {
+                const float x0 = xw[q][1 + j], x1 = xw[q][2 + j];
+                acc[q] += x0 * c0;
+                acc[q] += x1 * c1;
+            }
+        }
+        if (j < D.rmax) {
+            const float c = rrow[j];
+            for (int q = 0; q < kDownPerThread; q++) acc[q] += xw[q][1 + j] * c;
+        }
     }
     for (int q = 0; q < kDownPerThread; q++) {
         const uint32_t wl = w + q * kGroups, v = v0 + wl;
-        const bool voiced = v < D.nvoices && min(D.nframes[v < D.nvoices ? v : 0], D.max_nframes) > 0;
-        uint32_t nout = voiced ? (uint32_t)src_count_outputs(sNt[wl], pad, inc) : 0u;
-        if (D.stream) nout = v < D.nvoices ? D.k_end : 0u;
+        // (the voice's output count was put in number_samples by trm_down_count_kernel: the closed form is four 64-bit
+        // divisions, and evaluated here -- per thread and voice, as rounds 1-3 did -- it cost ten times the products)
+        const uint32_t nout = noutOf[q];
         float m = 0.0f;
+#if defined(TRM_EXP_DOWN) && TRM_EXP_DOWN == 5
+        if (k < nout && acc[q] == 12345.678f) {
+#else
         if (k < nout) {
-            (D.out + D.out_offset[v])[k - D.k_base] = acc[q];
+#endif
+            outRow[q][k - D.k_base] = acc[q];
             m = fabsf(acc[q]);
         }
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));     // the 32 lanes of this voice
+        for (int off = kDownCols / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));     // the lanes of this voice
         if (o == 0 && v < D.nvoices) {
             if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(&D.max_sample[v]), __float_as_uint(m));
-            if (blockIdx.x == 0) D.number_samples[v] = nout - D.k_base;
         }
     }
+}
+
+// number_samples[v] of a down-sampling launch (what trm_downsample_rows_kernel's workgroups mask their stores with):
+// the outputs of a voice of (nframes - 1) * controlPeriod tube samples (src_count_outputs), a chunk's k_end - k_base
+__global__ __launch_bounds__(256) void trm_down_count_kernel(const Const C, const DownArgs D)
+{
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= D.nvoices) return;
+    const uint32_t nfr = min(D.nframes[v], D.max_nframes);
+    uint32_t nout = nfr > 0 ? (uint32_t)src_count_outputs((uint64_t)(nfr - 1) * (uint32_t)C.controlPeriod, (uint32_t)C.padSize, C.timeRegisterIncrement) : 0u;
+    if (D.stream) nout = D.k_end;
+    D.number_samples[v] = nout - D.k_base;
 }
 
 // Output normalisation (TRMTubeModel.m:370-389 file path, :515-533 WAV-data path).  One
@@ -890,9 +968,11 @@ hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stre
         if (a.stream) noutMax = a.k_end - a.k_base;
         hipError_t e = hipMemsetAsync(a.max_sample, 0, a.nvoices * sizeof(float), stream);
         if (e != hipSuccess) return e;
-        const dim3 grid((unsigned)((noutMax + kDownCols - 1) / kDownCols > 0 ? (noutMax + kDownCols - 1) / kDownCols : 1),
-                        (a.nvoices + kDownVoices - 1) / kDownVoices);
-        hipLaunchKernelGGL(trm_downsample_rows_kernel, grid, dim3(kDownCols * kDownVoices / kDownPerThread), lds, stream, c, a, xlen);
+        DownArgs t = a;
+        t.ntiles = (uint32_t)((noutMax + kDownCols - 1) / kDownCols > 0 ? (noutMax + kDownCols - 1) / kDownCols : 1);
+        const dim3 grid((t.ntiles + 7u) & ~7u, (a.nvoices + kDownVoices - 1) / kDownVoices);
+        hipLaunchKernelGGL(trm_down_count_kernel, dim3((a.nvoices + 255) / 256), dim3(256), 0, stream, c, t);
+        hipLaunchKernelGGL(trm_downsample_rows_kernel, grid, dim3(kDownCols * kDownVoices / kDownPerThread), lds, stream, c, t, xlen);
         return hipGetLastError();
     }
     if (a.stream) return hipErrorInvalidValue;       // (the generic kernel converts whole utterances only)

@@ -384,7 +384,8 @@ int  trm_batch_last_kernel(const trm_batch *batch);
  *   TRM_TIME_SPLIT_OFF             whole utterances always;
  *   periods > 0                    segments of that many control periods (TRM_ERANGE when the tube never forgets:
  *                                  lossFactor 0).
- * Down-sampling batches (tube rate above the output rate) are never split.  A control track whose frication bandwidth
+ * Down-sampling batches (tube rate above the output rate) split the same way: the segments write their stretches of the
+ * tube-rate rows and the down-sampling kernel converts them as ever.  A control track whose frication bandwidth
  * falls below what the warm-up covers (some tens of Hz; Monet's minimum is 250) is found on the device before the launch
  * and the batch then runs as whole utterances -- the call stays asynchronous either way.  The environment variable
  * TRM_TIME_SPLIT=off|auto|<periods>, read when a batch object is created, sets the default (diagnostics, tests).

@@ -163,6 +163,28 @@ def test_split_ragged_batch_against_oracle(g):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rate", [16000.0, 8000.0, 22050.0])
+def test_split_down_sampling_batch(g, rate):
+    """Tube rate above the output rate (a 12.5 cm tube at 22.05 kHz; Monet's tube into 16 / 8 kHz): the segments write their
+    stretches of the tube-rate rows, the down-sampling kernel converts them.  Ragged voices against the oracle, counts exact
+    (incl. the reference's extra converter lap where it occurs)."""
+    pd = cases.monet_default_params(rate)
+    if rate == 22050.0:
+        pd["length"] = 12.5
+    rows = cases.load_gnuspeech_rows()
+    voices = [rows[i:i + 40 + 3 * i].copy() for i in range(0, 70)] + [np.zeros((0, 16)), rows[9:10].copy()]
+    b = _batch(g, pd, 11)
+    pcm, ns, mx = b.synthesize(voices)
+    assert b.last_time_split[0] == 11
+    op = O.InputParams.from_dict(pd)
+    for v, fr in enumerate(voices):
+        o = O.synthesize(op, np.asarray(fr, dtype=np.float32).astype(np.float64))
+        assert int(ns[v]) == o["numberSamples"], v
+        if o["numberSamples"] and o["maximumSampleValue"] > 0:
+            assert nrms(pcm[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL, v
+
+
+@pytest.mark.gpu
 def test_split_equals_whole_to_rounding_and_is_deterministic(g):
     """The split launch against the whole-utterance launch of the same kernel form: far inside the tolerance (what the
     warm-up leaves: 1e-6 of the forgotten state), and bit-identical from launch to launch."""

@@ -3,7 +3,7 @@
 # on the GPU box -> gpurun_out/prof_$TAG/summary.txt (+ the bench line of the same command).
 #   usage: [TRM_SUMMARY_DISPATCHES=2] tools/profile_workload.sh TAG <bench.py workload flags...>       e.g.  wide65536 --voices 65536 --kernel wide
 #   (TRM_SUMMARY_DISPATCHES: dispatches per launch -- 2 for 131 072 voices of the one-voice-per-lane kernel, tools/rocprof_summary.py)
-# tools/make_traffic.py turns summary.txt into an entry of profiles/traffic_r03.json.
+# tools/make_traffic.py turns summary.txt into an entry of profiles/traffic_r04.json.
 set -e
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
