@@ -108,7 +108,7 @@ struct trm_batch {
     // time-split launches (trm_batch_set_time_split)
     int splitSetting = TRM_TIME_SPLIT_AUTO;      // AUTO, OFF, or a segment length in control periods
     uint32_t lastSplitPeriods = 0, lastSplitWarm = 0;      // what the last launch did (0: whole utterances)
-    DevBuf<double> dSegPhase;
+    DevBuf<double> dSegPhase, dPeriodAdv;
     uint32_t *dGate = nullptr;
     uint64_t hintTotalPeriods = 0;       // set by the host-buffer entries (they see every voice's length) for the launch that follows
 };
@@ -624,12 +624,12 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         const uint32_t nseg = (max_nframes - 1 + pl.periods - 1) / pl.periods;
         const uint32_t wgPerSeg = (uint32_t)((nvoices + 63) / 64);
         if ((uint64_t)nseg * wgPerSeg > 0x7FFFFFFFull / 64) return fail(TRM_ERANGE, "time split: too many segments");
-        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * 64))) return rc;
+        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * 64)) || (rc = b->dPeriodAdv.reserve(nvoices * (size_t)max_nframes))) return rc;
         HIP_TRY(hipMemsetAsync(b->dGate, 0, sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_max_sample, 0, nvoices * sizeof(float), stream));
         trm::PhaseArgs ph;
         ph.frames = d_frames; ph.frame_offset = d_frame_offset; ph.nframes = d_nframes;
-        ph.seg_phase = b->dSegPhase.p; ph.gate = b->dGate; ph.bw_floor = pl.bwFloor;
+        ph.period_adv = b->dPeriodAdv.p; ph.seg_phase = b->dSegPhase.p; ph.gate = b->dGate; ph.bw_floor = pl.bwFloor;
         ph.nvoices = (uint32_t)nvoices; ph.max_nframes = max_nframes; ph.nseg = nseg;
         ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg;
         HIP_TRY(trm::launch_phase(b->c, ph, stream));

@@ -49,7 +49,7 @@ struct TubeArgs {
     // from REST, seg_warm control periods before the segment's first one (the tube forgets like its slowest pole:
     // trm_capi.cc plan_time_split), and emits the converter outputs whose read position lies in the segment proper.  What a
     // segment cannot reconstruct from the frames is the oscillator position: seg_phase[q * 64 * seg_wg_per_seg + v] is the
-    // (wrapped) advance of voice v's oscillator between the warm-up starts of segments q - 1 and q (trm_phase_kernel);
+    // (wrapped) advance of voice v's oscillator between the warm-up starts of segments q - 1 and q (trm_phase_segment_kernel);
     // the kernel sums q = 1 .. its own segment (exact sums: osc_increment).  max_sample is folded with an atomic max
     // (zeroed by the launcher), number_samples written by segment 0.
     uint32_t seg_periods = 0, seg_warm = 0, seg_wg_per_seg = 0;
@@ -61,13 +61,14 @@ struct TubeArgs {
     uint32_t gate_want = 0;
 };
 
-// trm_phase_kernel: the oscillator advances a time-split launch starts from, and the guard that decides whether the batch
+// trm_phase_*_kernel: the oscillator advances a time-split launch starts from, and the guard that decides whether the batch
 // may be split at all: *gate is set when a frame's frication bandwidth lies below bw_floor (the band-pass then remembers
 // longer than the warm-up; whole-utterance launch instead).  `nseg` = segments of the longest voice.
 struct PhaseArgs {
     const float *frames;
     const uint64_t *frame_offset;
     const uint32_t *nframes;
+    double *period_adv;           // scratch, nvoices * max_nframes doubles: the oscillator's advance per (voice, control period)
     double *seg_phase;
     uint32_t *gate;
     float bw_floor;

@@ -333,6 +333,15 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         const int u = role - 2;
         __builtin_amdgcn_s_setprio(TRM_PRIO_COEF);
         CoefTrack T;
+        // the stage's constants as vector registers (cf. the tube wave's TubeConst): ~14 of the stage's 119 instructions per
+        // sample read one, and with a scalar operand they issue at the slow rate (VERDICT r03 asked for this A/B in the
+        // throughput waves: 65 536 voices 16.03 -> 15.87 ms, -1.0 %, profiles/ab_r04.txt)
+        CoefConst CC;
+        {
+            auto vcopy = [](float s) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s)); return r; };
+            CC.damping = vcopy(C.damping); CC.apScaleSq = vcopy(C.apScaleSq); CC.mA10 = vcopy(C.mA10);
+            CC.noseR1sq = vcopy(C.noseR1sq); CC.invSampleRate = vcopy(C.invSampleRate); CC.fricGain = vcopy(C.fricGain);
+        }
         auto frame_at = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
         // position of this wave's next sample in its control period; the first sample starts period 1
         uint32_t j = CP + (uint32_t)u, f = 0;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
                     load_frame(frames, frame_at(f), cur, 4);
                     coef_track_setup(T, C, prev, cur);
                 }
-                Coefs K = coef_sample<kStream>(T, C, (int)j);
+                Coefs K = coef_sample<kStream>(T, CC, (int)j);
                 j += kTB;
                 // 20 floats per sample: C8, alphaLR and bpAlpha are re-derived by the tube wave (1 op each)
                 float4 *dst = &sK[((buf * kTB + u) * kKQuads) * kWave + lane];
@@ -622,52 +631,76 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     }
 }
 
-// Prefix pass of a time-split launch (TubeArgs::seg_*).  Thread (q, v), q = 0 .. nseg - 1, walks voice v's control periods
-// between the warm-up starts of segments q and q + 1 (the last q: to the utterance's end):
-//   * the oscillator's advance over them -- the same track set-up, increments and wraps as osc_sample, position only
-//     (TRMWavetable.m:165-181) -- goes to seg_phase[q + 1][v]: the tube kernel's segment s sums entries 1 .. s;
-//   * a frame whose frication bandwidth lies below bw_floor sets *gate: that band-pass remembers longer than the
-//     warm-up, and the batch runs as whole utterances instead (TubeArgs::gate).
-__global__ __launch_bounds__(256) void trm_phase_kernel(const Const C, const PhaseArgs P)
+// Prefix pass of a time-split launch (TubeArgs::seg_*), two kernels.
+//   trm_phase_period_kernel   thread (v, p): the oscillator's advance over voice v's control period p, in units of 2^-30 table
+//       entries -- the same track set-up and increments as osc_sample (TRMWavetable.m:165-181, osc_increment), summed as
+//       integer-valued doubles (every term < 2^35, 79-200 of them: exact) and reduced modulo the table (512 * 2^30) --
+//       to period_adv[v * max_nframes + p]; and the guard: a frame whose frication bandwidth lies below bw_floor sets *gate
+//       (that band-pass remembers longer than the warm-up: the batch runs as whole utterances instead, TubeArgs::gate).
+//   trm_phase_segment_kernel  thread (q, v): the sum of period_adv over the periods between the warm-up starts of segments
+//       q and q + 1, as a table position in (-1, 511] (mod0's range, TRMWavetable.m:28-34), to seg_phase[q + 1][v]; the tube
+//       kernel's segment s sums entries 1 .. s.  Sums and wraps of exact values: the position a segment starts from is
+//       bit for bit the one the uninterrupted oscillator has there.
+// (Round 4's first version walked every segment's periods serially in one thread: 0.33-0.43 ms of a 2.7-3.3 ms launch.)
+constexpr double kPhaseModulus = 549755813888.0;       // 512 * 2^30
+__global__ __launch_bounds__(256) void trm_phase_period_kernel(const Const C, const PhaseArgs P)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t pitch = P.max_nframes;              // periods per voice in period_adv (max_nframes - 1 used)
+    const uint32_t v = idx / pitch, p = idx - v * pitch;
+    if (v >= P.nvoices) return;
+    const uint32_t nfr = min(P.nframes[v], P.max_nframes);
+    if (p + 1 >= nfr) {
+        // (no period here; the voice's last frame still counts for the guard)
+        if (nfr > 0 && p + 1 == nfr && (P.frames + P.frame_offset[v] * 16)[(size_t)p * 16 + 6] < P.bw_floor) atomicOr(P.gate, 1u);
+        return;
+    }
+    const float *frames = P.frames + P.frame_offset[v] * 16;
+    float prev[4], cur[4];
+    load_frame(frames, p, prev, 1);
+    load_frame(frames, p + 1, cur, 1);
+    if (frames[(size_t)p * 16 + 6] < P.bw_floor) atomicOr(P.gate, 1u);
+    ExciteTrack T;
+    excite_track_setup(T, C, prev, cur);
+    double sum = 0.0;
+    const uint32_t CP = (uint32_t)C.controlPeriod;
+    for (uint32_t j = 0; j < CP; j++) {
+        // osc_increment's rounded product, left in its integer units: (f0 * 0.5) * basicIncrement * 2^30 -- the factors
+        // 0.5 and 2^30 are exact, so this is the same rounding of f0 * basicIncrement
+        sum += rint_d(((T.f0 * 0.5) * C.basicIncrement) * 1073741824.0);
+        T.f0 *= T.f0Ratio;
+    }
+    sum += sum;                                         // two increments per tube sample (2x oversampled oscillator, :178-181)
+    sum -= kPhaseModulus * floor(sum * (1.0 / kPhaseModulus));
+    sum = sum < 0.0 ? sum + kPhaseModulus : sum;        // (the quotient's rounding at an exact multiple)
+    sum = sum >= kPhaseModulus ? sum - kPhaseModulus : sum;
+    P.period_adv[(size_t)v * pitch + p] = sum;
+}
+
+__global__ __launch_bounds__(256) void trm_phase_segment_kernel(const Const C, const PhaseArgs P)
 {
     const uint32_t lanes = P.seg_wg_per_seg * kWave;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = idx / lanes, v = idx - q * lanes;
-    if (q >= P.nseg || v >= P.nvoices) return;
+    if (q + 1 >= P.nseg || v >= P.nvoices) return;
     const uint32_t nfr = min(P.nframes[v], P.max_nframes);
-    const uint32_t nper = nfr > 0 ? nfr - 1 : 0, CP = (uint32_t)C.controlPeriod;
+    const uint32_t nper = nfr > 0 ? nfr - 1 : 0;
     auto warm_start = [&](uint32_t sgm) {
         const uint32_t p = sgm * P.seg_periods;
         return p > P.seg_warm ? p - P.seg_warm : 0u;
     };
-    uint32_t lo = warm_start(q), hi = q + 1 < P.nseg ? warm_start(q + 1) : nper;
+    uint32_t lo = warm_start(q), hi = warm_start(q + 1);
     lo = lo < nper ? lo : nper;
     hi = hi < nper ? hi : nper;
-    const float *frames = P.frames + P.frame_offset[v] * 16;
-    bool narrow = false;
-    double pos = 0.0;
-    float prev[4], cur[4];
-    if (nfr > 0) {
-        load_frame(frames, lo, cur, 1);
-        narrow = frames[(size_t)lo * 16 + 6] < P.bw_floor;
+    const double *adv = P.period_adv + (size_t)v * P.max_nframes;
+    double sum = 0.0;
+    for (uint32_t p = lo; p < hi; p++) {
+        sum += adv[p];                                  // (integers below 2^39, at most a few thousand of them: exact)
+        sum = sum >= kPhaseModulus ? sum - kPhaseModulus : sum;
     }
-    for (uint32_t f = lo + 1; f <= hi; f++) {
-        for (int i = 0; i < 4; i++) prev[i] = cur[i];
-        load_frame(frames, f, cur, 1);
-        narrow = narrow || frames[(size_t)f * 16 + 6] < P.bw_floor;
-        ExciteTrack T;
-        excite_track_setup(T, C, prev, cur);
-        for (uint32_t j = 0; j < CP; j++) {
-            const double inc = osc_increment(T.f0, C);
-            double p1 = pos + inc;
-            p1 = p1 > 511.0 ? p1 - 512.0 : p1;
-            double p2 = p1 + inc;
-            pos = p2 > 511.0 ? p2 - 512.0 : p2;
-            T.f0 *= T.f0Ratio;
-        }
-    }
-    if (q + 1 < P.nseg) P.seg_phase[(size_t)(q + 1) * lanes + v] = pos;
-    if (narrow) atomicOr(P.gate, 1u);
+    double pos = sum * (1.0 / 1073741824.0);            // exact: [0, 512)
+    pos = pos > 511.0 ? pos - 512.0 : pos;              // mod0's representative
+    P.seg_phase[(size_t)(q + 1) * lanes + v] = pos;
 }
 
 // Down-sampling branch of the converter (TRMSampleRateConverter.m:234-297): one workgroup per voice,
@@ -941,8 +974,10 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
 hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0 || a.nseg == 0) return hipSuccess;
-    const uint64_t threads = (uint64_t)a.nseg * a.seg_wg_per_seg * kWave;
-    hipLaunchKernelGGL(trm_phase_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c, a);
+    const uint64_t periods = (uint64_t)a.nvoices * a.max_nframes;
+    hipLaunchKernelGGL(trm_phase_period_kernel, dim3((unsigned)((periods + 255) / 256)), dim3(256), 0, stream, c, a);
+    const uint64_t threads = (uint64_t)(a.nseg - 1) * a.seg_wg_per_seg * kWave;
+    if (threads > 0) hipLaunchKernelGGL(trm_phase_segment_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }
 

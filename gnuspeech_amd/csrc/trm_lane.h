@@ -393,7 +393,15 @@ TRM_HD void coef_track_setup(CoefTrack &T, const Const &C, const float *prev, co
 // Two halves that touch disjoint fields of Coefs (they may run in different waves):
 //   coef_sample_area   radii, velum -> scattering coefficients, three-way junction, NC1
 //   coef_sample_fric   frication volume / position / band -> taps, band-pass coefficients
-TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j)
+// CT: where the stage's wave-uniform constants come from -- `Const` (kernel arguments: scalar registers) or a CoefConst of
+// vector-register copies (cf. TubeConst): an instruction with a scalar operand issues at the 4.3-cycle rate on a shared SIMD,
+// a plain one at 2.4 (tools/ubench/valu_ceiling.hip).
+struct CoefConst {
+    float damping, apScaleSq, mA10, noseR1sq, invSampleRate, fricGain;
+};
+
+template <class CT>
+TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const CT &C, int j)
 {
     const float fj = (float)j;
     // control-rate interpolation (:676-688 evaluated as base + j*delta)
@@ -423,8 +431,8 @@ TRM_HD void coef_sample_area(Coefs &K, const CoefTrack &T, const Const &C, int j
 // kSatTaps: "max(., 0)" as the [0, 1] clamp of the FMA that forms the tap -- two operations per tap instead of three; only
 // without the gain (the amplitude is at most 1 then) and only where it pays: the one-voice-per-lane kernel (8 of its 450
 // instructions per sample); the eight-lane kernel's frication wave ran 3 % SLOWER with it (profiles/ab_r03.txt).
-template <bool kFricGain = false, bool kSatTaps = false>
-TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j)
+template <bool kFricGain = false, bool kSatTaps = false, class CT = Const>
+TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const CT &C, int j)
 {
     const float fj = (float)j;
     float fricDb = fma_f(fj, T.delta[0], T.base[0]);
@@ -467,12 +475,12 @@ TRM_HD void coef_sample_fric(Coefs &K, const CoefTrack &T, const Const &C, int j
     K.pad_ = 0.0f;
 }
 
-template <bool kFricGain = false>
-TRM_HD Coefs coef_sample(const CoefTrack &T, const Const &C, int j)
+template <bool kFricGain = false, class CT = Const>
+TRM_HD Coefs coef_sample(const CoefTrack &T, const CT &C, int j)
 {
     Coefs K;
     coef_sample_area(K, T, C, j);
-    coef_sample_fric<kFricGain, !kFricGain>(K, T, C, j);
+    coef_sample_fric<kFricGain, !kFricGain, CT>(K, T, C, j);
     return K;
 }
 
