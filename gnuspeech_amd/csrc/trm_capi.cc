@@ -458,7 +458,7 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
     if (setting > 0) periods = (uint32_t)setting;
     else {
         // AUTO.  A time-split launch pays when its workgroups -- one per segment and block of 64 voices -- find room on the
-        // chip at once: the one-voice-per-lane kernel runs one workgroup per CU at 6.6 and two at 7.9 ms per second of
+        // chip at once: the one-voice-per-lane kernel runs one workgroup per CU at 6.7 and two at 7.5 ms per second of
         // speech, and a launch that needs a second round of workgroups loses what the split gained (measured:
         // profiles/split_probe_r04.txt).  So: the two segment counts that fill one resp. two workgroups per CU, the
         // shorter predicted launch of the two, taken when it beats whole utterances by a tenth.
@@ -485,7 +485,8 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
             }
             const uint32_t sp = lo;
             if (sp >= P) continue;
-            const double t = 0.08 + (perCu == 1 ? 6.6 : 7.9) * (double)(sp + warm) * CP / 19750.0 * 1.04;
+            // (measured, profiles/split_probe_r04.txt: one workgroup per CU 6.4-6.7 ms per second of speech, two 7.2-7.6)
+            const double t = 0.03 + (perCu == 1 ? 6.7 : 7.5) * (double)(sp + warm) * CP / 19750.0;
             if (t < best) { best = t; periods = sp; }
         }
     }
