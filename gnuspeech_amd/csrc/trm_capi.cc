@@ -440,6 +440,14 @@ static double unsplit_cost(const trm_batch *b, size_t nvoices, int which)
     return vpc <= 64 ? 6.5 : vpc <= 128 ? 7.8 : 7.8 * vpc / 128.0;
 }
 
+// segments of an utterance of P control periods cut every `periods`: the first one is periods + warm long (it has no warm-up
+// of its own: with it that long every workgroup of the launch runs periods + warm control periods)
+static uint32_t split_segments(uint32_t P, uint32_t periods, uint32_t warm)
+{
+    const uint32_t first = periods + warm;
+    return P <= first ? 1u : 1u + (P - first + periods - 1) / periods;
+}
+
 // `which` = the kernel form the launch would take unsplit.  `totalPeriods` = the control periods of all voices together where
 // the caller knows them (the host-buffer entries; 0: every voice is taken to be as long as the longest).
 static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, uint64_t totalPeriods, SplitPlan &pl)
@@ -470,9 +478,10 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
         uint32_t minPeriods = (255u + CP) / CP > 4u ? (255u + CP) / CP : 4u;
         minPeriods = minPeriods > (warm + 1) / 2 ? minPeriods : (warm + 1) / 2;
         for (int perCu = 1; perCu <= 2; perCu++) {
-            // workgroups of a launch cut every sp periods: per segment the blocks of 64 voices that reach it
+            // workgroups of a launch cut every sp periods (the first segment sp + warm: split_segments): per segment the
+            // blocks of 64 voices that reach it
             auto workgroups = [&](uint32_t sp) -> uint64_t {
-                const uint64_t nseg = (P + sp - 1) / sp;
+                const uint64_t nseg = split_segments(P, sp, warm);
                 if (totalPeriods == 0) return nseg * ((nvoices + 63) / 64);
                 return (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (nseg + 1) / 2;      // (+ the segments' partly filled last blocks)
             };
@@ -484,13 +493,13 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
                 if (workgroups(mid) <= (uint64_t)(perCu * cus)) hi = mid; else lo = mid + 1;
             }
             const uint32_t sp = lo;
-            if (sp >= P) continue;
+            if (split_segments(P, sp, warm) < 2) continue;
             // (measured, profiles/split_probe_r04.txt: one workgroup per CU 6.4-6.7 ms per second of speech, two 7.2-7.6)
             const double t = 0.03 + (perCu == 1 ? 6.7 : 7.5) * (double)(sp + warm) * CP / 19750.0;
             if (t < best) { best = t; periods = sp; }
         }
     }
-    if (periods == 0 || periods >= P) return TRM_OK;                     // one segment is the whole utterance
+    if (periods == 0 || split_segments(P, periods, warm) < 2) return TRM_OK;      // one segment is the whole utterance
     pl.periods = periods;
     pl.warm = warm;
     {
@@ -622,7 +631,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     b->lastSplitPeriods = pl.periods;
     b->lastSplitWarm = pl.periods ? pl.warm : 0;
     if (pl.periods) {
-        const uint32_t nseg = (max_nframes - 1 + pl.periods - 1) / pl.periods;
+        const uint32_t nseg = split_segments(max_nframes - 1, pl.periods, pl.warm);
         const uint32_t wgPerSeg = (uint32_t)((nvoices + 63) / 64);
         if ((uint64_t)nseg * wgPerSeg > 0x7FFFFFFFull / 64) return fail(TRM_ERANGE, "time split: too many segments");
         if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * 64)) || (rc = b->dPeriodAdv.reserve(nvoices * (size_t)max_nframes))) return rc;
@@ -632,10 +641,11 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         ph.frames = d_frames; ph.frame_offset = d_frame_offset; ph.nframes = d_nframes;
         ph.period_adv = b->dPeriodAdv.p; ph.seg_phase = b->dSegPhase.p; ph.gate = b->dGate; ph.bw_floor = pl.bwFloor;
         ph.nvoices = (uint32_t)nvoices; ph.max_nframes = max_nframes; ph.nseg = nseg;
-        ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg;
+        ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg; ph.seg_first = pl.periods + pl.warm;
         HIP_TRY(trm::launch_phase(b->c, ph, stream));
         trm::TubeArgs sa = a;
         sa.seg_periods = pl.periods; sa.seg_warm = pl.warm; sa.seg_wg_per_seg = wgPerSeg; sa.seg_grid = nseg * wgPerSeg;
+        sa.seg_first = pl.periods + pl.warm;
         sa.seg_phase = b->dSegPhase.p;
         sa.gate = b->dGate; sa.gate_want = 0;
         HIP_TRY(trm::launch_tube(b->c, sa, stream));

@@ -53,6 +53,9 @@ struct TubeArgs {
     // the kernel sums q = 1 .. its own segment (exact sums: osc_increment).  max_sample is folded with an atomic max
     // (zeroed by the launcher), number_samples written by segment 0.
     uint32_t seg_periods = 0, seg_warm = 0, seg_wg_per_seg = 0;
+    uint32_t seg_first = 0;           // control periods of segment 0 (= seg_periods + seg_warm: it needs no warm-up, so it is that much
+                                      // longer and every workgroup runs the same number of periods); segment s >= 1 starts at
+                                      // seg_first + (s - 1) * seg_periods
     uint32_t seg_grid = 0;            // workgroups of the launch: seg_wg_per_seg * (segments of the longest voice)
     const double *seg_phase = nullptr;
     // Device-side choice between two launches of one batch (time-split vs whole utterances): a kernel with a gate returns
@@ -72,7 +75,7 @@ struct PhaseArgs {
     double *seg_phase;
     uint32_t *gate;
     float bw_floor;
-    uint32_t nvoices, max_nframes, nseg, seg_periods, seg_warm, seg_wg_per_seg;
+    uint32_t nvoices, max_nframes, nseg, seg_periods, seg_warm, seg_wg_per_seg, seg_first;
 };
 hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream);
 

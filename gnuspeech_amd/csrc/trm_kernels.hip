@@ -155,17 +155,20 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     // converter outputs with a read position before tube sample `end`: k < outputs_before(end) (trm_capi.cc outputs_through)
     auto outputs_before = [&](uint64_t end) { return end == 0 ? 0u : (uint32_t)(((end << 16) - 1) / inc + 1); };
 
+    // segment s covers the control periods seg_begin(s) .. seg_begin(s + 1): the first segment is a warm-up longer than the
+    // others (it has none of its own), so that every workgroup of the launch runs the same number of periods
+    auto seg_begin = [&](uint32_t sgm) { return sgm == 0 ? 0u : A.seg_first + (sgm - 1) * A.seg_periods; };
     const uint32_t nfrAll = min(A.nframes[v], A.max_nframes);
     // the frames this launch runs for this lane: the utterance's, or those of the workgroup's segment with its warm-up
     uint32_t nfr = nfrAll, segFrame0 = 0, segOutEnd = 0;
     bool segLast = true;
     if (kSeg) {
         const uint32_t nper = nfrAll > 0 ? nfrAll - 1 : 0;
-        const uint32_t pLo = seg * A.seg_periods;
+        const uint32_t pLo = seg_begin(seg), pEnd = seg_begin(seg + 1);
         segFrame0 = pLo > A.seg_warm ? pLo - A.seg_warm : 0u;                      // (uniform)
         if (seg > 0 && pLo >= nper) nfr = 0;                                       // the voice ended before this segment
         else if (nfrAll > 0) {
-            const uint32_t pHi = pLo + A.seg_periods < nper ? pLo + A.seg_periods : nper;
+            const uint32_t pHi = pEnd < nper ? pEnd : nper;
             nfr = pHi - segFrame0 + 1;
             segLast = pHi == nper;
             segOutEnd = outputs_before((uint64_t)pHi * CP);                        // (used when the voice goes on)
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     // (segments: a workgroup's lanes either end inside the segment -- their flush follows -- or run to its end: nTotal
     // carries the flush's 2*pad samples either way, lanes that go on stop emitting at segOutEnd)
     const uint32_t nBase = kStream ? A.stream_n_base : kSeg ? segFrame0 * CP : 0u;
-    const uint32_t kBase = kStream ? A.stream_k_base : kSeg ? outputs_before((uint64_t)seg * A.seg_periods * CP) : 0u;
+    const uint32_t kBase = kStream ? A.stream_k_base : kSeg ? outputs_before((uint64_t)seg_begin(seg) * CP) : 0u;
     // this voice's state record: per workgroup a block of [kStreamFloats fields][64 lanes] floats -- a wave's 64 lanes touch
     // 64 consecutive floats per field (voice-major records cost 64 cache lines per field and instruction) and a field is a
     // CONSTANT 256 bytes from the one before (one base address per lane: per-field 64-bit strides cost the streaming
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
                 // a segment writes its own stretch of the voice's tube-rate row (global index nBase + n), not its warm-up's;
                 // the voice's last segment appends the flush
                 const uint32_t gn = nBase + n;
-                if (tubeOut && laneValid && gn >= seg * A.seg_periods * CP && n < ntubeLane + (segLast ? 2u * (uint32_t)C.padSize : 0u))
+                if (tubeOut && laneValid && gn >= seg_begin(seg) * CP && n < ntubeLane + (segLast ? 2u * (uint32_t)C.padSize : 0u))
                     tubeOut[gn] = y;
             } else if (tubeOut && laneValid && n < ntubeLane + (sLast ? 2u * (uint32_t)C.padSize : 0u)) tubeOut[n] = y;
         };
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(256) void trm_phase_segment_kernel(const Const C, c
     const uint32_t nfr = min(P.nframes[v], P.max_nframes);
     const uint32_t nper = nfr > 0 ? nfr - 1 : 0;
     auto warm_start = [&](uint32_t sgm) {
-        const uint32_t p = sgm * P.seg_periods;
+        const uint32_t p = sgm == 0 ? 0u : P.seg_first + (sgm - 1) * P.seg_periods;
         return p > P.seg_warm ? p - P.seg_warm : 0u;
     };
     uint32_t lo = warm_start(q), hi = warm_start(q + 1);

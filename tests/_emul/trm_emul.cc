@@ -89,7 +89,7 @@ extern "C" int trm_emul_synthesize_tract(const trm_input_params *p, const float 
 
 // ---------------------------------------------------------------------------------------------
 // Time-split synthesis (the host model of trm_kernels.hip's segment instance): the utterance is cut every `segPeriods`
-// control periods; every segment after the first starts from REST `warmPeriods` control periods early -- only the
+// control periods (the first segment is segPeriods + warmPeriods long); every segment after the first starts from REST `warmPeriods` control periods early -- only the
 // oscillator position is the true one (an exact prefix sum, osc_increment) and the noise sequence is addressed by its
 // index -- and the converter outputs whose read position lies in the segment proper are taken from it.  What the warm-up
 // forgets decays like the tube's slowest pole (damping^n for a closed tract); tests/test_quad_model.py and
@@ -139,9 +139,12 @@ extern "C" int trm_emul_synthesize_split(const trm_input_params *p, const float 
     const uint64_t total = count_outputs(d, ntube);
     auto outputs_through = [&](uint64_t endSample) { return endSample == 0 ? 0ull : ((endSample << 16) - 1) / inc + 1; };
     float mx = 0.f;
-    const size_t nseg = nper == 0 ? 1 : (nper + segPeriods - 1) / segPeriods;
+    // segment boundaries as the library lays them (trm_capi.cc split_segments): the first segment is segPeriods + warmPeriods long
+    auto seg_begin = [&](size_t sg) { return sg == 0 ? (size_t)0 : (size_t)segPeriods + warmPeriods + (sg - 1) * segPeriods; };
+    size_t nseg = 1;
+    while (seg_begin(nseg) < nper) nseg++;
     for (size_t sg = 0; sg < nseg; sg++) {
-        const size_t pLo = sg * segPeriods, pHi = pLo + segPeriods < nper ? pLo + segPeriods : nper;
+        const size_t pLo = seg_begin(sg), pHi = seg_begin(sg + 1) < nper ? seg_begin(sg + 1) : nper;
         const size_t pStart = pLo > warmPeriods ? pLo - warmPeriods : 0;
         const size_t nBase = pStart * CP, nLocal = (pHi - pStart) * CP;
         const bool last = sg + 1 == nseg;

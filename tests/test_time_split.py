@@ -114,22 +114,24 @@ def _batch(g, pd, split):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", UP_CASES)
-@pytest.mark.parametrize("seg", [9, 40])
+@pytest.mark.parametrize("seg", [5, 9, 40])
 def test_split_launch_matches_reference_fixture(g, name, seg):
     """Every up-sampling fixture, cut every `seg` control periods, against what the reference's C tube produced."""
     gold = golden_io.load(name)
     b = _batch(g, gold["params_dict"], seg)
-    pcm, ns, mx = b.synthesize([gold["frames"], gold["frames"][:seg + 3].copy(), gold["frames"][:2].copy()])
+    pcm, ns, mx = b.synthesize([gold["frames"], gold["frames"][:seg + 40].copy(), gold["frames"][:2].copy()])
     nper = len(gold["frames"]) - 1
-    assert b.last_time_split[0] == (seg if seg < nper else 0)         # (a fixture of at most `seg` periods is one segment: whole)
-    assert b.last_kernel == ("wide" if seg < nper else "oct")
+    warm = warm_periods(gold["params_dict"], int(gold["derived"][0]))
+    split = nper > seg + warm            # (the first segment is seg + warm periods long: a shorter fixture is one segment, whole)
+    assert b.last_time_split == ((seg, warm) if split else (0, 0))
+    assert b.last_kernel == ("wide" if split else "oct")
     assert int(ns[0]) == gold["numberSamples"]
     m = gold["maximumSampleValue"]
     assert nrms(pcm[0], gold["samples_f32"].astype(np.float64), m) <= RMS_TOL
     assert abs(float(mx[0]) - m) / m < 2e-4 and float(mx[0]) == float(np.abs(pcm[0]).max())
     # the two shorter voices of the launch (one ends in the second segment, one before the first ends) against the oracle
     for v in (1, 2):
-        fr = np.asarray(gold["frames"][:seg + 3] if v == 1 else gold["frames"][:2], dtype=np.float32)
+        fr = np.asarray(gold["frames"][:seg + 40] if v == 1 else gold["frames"][:2], dtype=np.float32)
         o = O.synthesize(gold["params"], fr.astype(np.float64))
         assert int(ns[v]) == o["numberSamples"]
         if o["maximumSampleValue"] > 0:
