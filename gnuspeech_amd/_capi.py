@@ -62,7 +62,7 @@ EXPORTS = [
     "trm_batch_synthesize_host", "trm_batch_synthesize_host_int16", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
     "trm_shard_voices", "trm_multi_create", "trm_multi_destroy", "trm_multi_synthesize_host", "trm_multi_synthesize_host_int16",
     "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
-    "trm_stream_push", "trm_stream_finish", "trm_stream_set_mode", "trm_stream_mode", "trm_stream_push_device", "trm_stream_finish_device", "trm_stream_kernel",
+    "trm_stream_push", "trm_stream_finish", "trm_stream_set_mode", "trm_stream_mode", "trm_stream_set_slice", "trm_stream_slice", "trm_stream_push_device", "trm_stream_finish_device", "trm_stream_kernel",
     "trm_events_count_frames", "trm_drift_seed_after", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
     "trm_batch_set_kernel", "trm_batch_last_kernel", "trm_batch_set_time_split", "trm_batch_last_time_split",
     "trm_batch_kernel_time_ms", "trm_batch_set_timing", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
@@ -146,6 +146,9 @@ def lib():
     L.trm_stream_kernel.argtypes = [vp]
     L.trm_stream_set_mode.argtypes = [vp, C.c_int]
     L.trm_stream_mode.argtypes = [vp]
+    L.trm_stream_set_slice.argtypes = [vp, C.c_uint32]
+    L.trm_stream_slice.argtypes = [vp]
+    L.trm_stream_slice.restype = C.c_uint32
     L.trm_events_count_frames.argtypes = [vp, C.c_size_t, C.POINTER(TrmIntonation), C.POINTER(C.c_size_t)]
     L.trm_drift_seed_after.argtypes = [C.c_float, C.c_size_t]
     L.trm_drift_seed_after.restype = C.c_float

@@ -709,6 +709,7 @@ struct trm_stream {
     int mode = TRM_STREAM_MODE_FRAMEWORK;
     bool wide = false;                // trm_kernels.hip's streaming instance (one voice per lane) instead of trm_quad.hip's
     uint64_t nBase = 0, kBase = 0;    // tube samples synthesized / converter outputs emitted so far
+    int32_t controlPeriod0 = 0;       // the control period the parameters derive (trm_stream_set_slice(.., 0) returns to it)
 };
 
 int trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out)
@@ -727,6 +728,7 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
     if (!s) { trm_batch_destroy(b); return fail(TRM_ENOMEM, "trm_stream"); }
     s->b = b;
     s->nvoices = nvoices;
+    s->controlPeriod0 = b->c.controlPeriod;
     // The kernel form is the stream's for life (the saved state is laid out for it): one voice per lane once the voices
     // fill the chip (and for what the four-lane form does not convert: more than four outputs per tube sample), four
     // lanes per voice below that.  TRM_TUBE_KERNEL=wide|quad overrides (diagnostics).
@@ -780,10 +782,36 @@ int trm_stream_set_mode(trm_stream *s, int mode)
     if (s->haveLast) return fail(TRM_EINVAL, "the stream's mode can only change between utterances (before the first push or after finish)");
     s->mode = mode;
     s->b->c.fricGain = mode == TRM_STREAM_MODE_TRACT ? 10.0f : 1.0f;      // Applications/TRAcT/tube.c:1371
+    if (mode != TRM_STREAM_MODE_TRACT && s->b->c.controlPeriod != s->controlPeriod0) {      // (slices are TRAcT order's)
+        s->mode = TRM_STREAM_MODE_TRACT;
+        int rc = trm_stream_set_slice(s, 0);
+        s->mode = mode;
+        if (rc) return rc;
+    }
     return TRM_OK;
 }
 
 int trm_stream_mode(const trm_stream *s) { return s ? s->mode : TRM_STREAM_MODE_FRAMEWORK; }
+
+int trm_stream_set_slice(trm_stream *s, uint32_t tube_samples)
+{
+    if (!s) return fail(TRM_EINVAL, "null stream");
+    if (s->mode != TRM_STREAM_MODE_TRACT) return fail(TRM_EINVAL, "a slice shorter than the control period needs held parameters: TRM_STREAM_MODE_TRACT");
+    if (s->haveLast) return fail(TRM_EINVAL, "the slice length can only change between utterances (before the first push or after finish)");
+    const uint32_t cp = tube_samples ? tube_samples : (uint32_t)s->controlPeriod0;
+    if (cp < 4 || cp > 0x100000u) return fail(TRM_EINVAL, "slice of %u tube samples", tube_samples);
+    // the kernels' "control period" is the run of samples one frame row stands for; nothing else of the tube depends on it
+    // (the sample rate and everything derived from it were fixed when the batch was created)
+    trm_batch *b = s->b;
+    b->c.controlPeriod = (int32_t)cp;
+    b->c.invControlPeriod = (float)(1.0 / cp);
+    b->c.invControlPeriodD = 1.0 / cp;
+    b->d.controlPeriod = (int32_t)cp;
+    s->shapeRows = 0;              // (the chunk shapes are in frames: re-upload the index arrays)
+    return TRM_OK;
+}
+
+uint32_t trm_stream_slice(const trm_stream *s) { return s ? (uint32_t)s->b->c.controlPeriod : 0u; }
 int trm_stream_kernel(const trm_stream *s) { return s ? (s->wide ? TRM_KERNEL_WIDE : TRM_KERNEL_QUAD) : TRM_KERNEL_AUTO; }
 
 size_t trm_stream_samples_for_push(const trm_stream *s, size_t nframes)

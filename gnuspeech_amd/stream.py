@@ -30,6 +30,14 @@ class TRMStream:
         (every frame one control period of held parameters, x10 frication taps, x100 output; tube.c:1096-1190, 1371)."""
         check(lib().trm_stream_set_mode(self._h, MODES[mode]))
 
+    def set_slice(self, tube_samples):
+        """"tract" mode only: the tube samples one pushed frame stands for (0 = a control period); see trm_stream_set_slice."""
+        check(lib().trm_stream_set_slice(self._h, int(tube_samples)))
+
+    @property
+    def slice(self):
+        return lib().trm_stream_slice(self._h)
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:

@@ -325,6 +325,14 @@ void trm_stream_destroy(trm_stream *stream);
  * Only between utterances (before the first push or after trm_stream_finish); TRM_EINVAL otherwise. */
 enum { TRM_STREAM_MODE_FRAMEWORK = 0, TRM_STREAM_MODE_TRACT = 1 };
 int  trm_stream_set_mode(trm_stream *stream, int mode);
+/* TRM_STREAM_MODE_TRACT only: the tube samples one pushed frame stands for (default: a control period).  tube.c reads its
+ * parameter set every SAMPLE (tube.c:1121-1136), so a slider write is heard at once; with whole control periods per push it is
+ * heard at the next period boundary, up to 10 ms later at TRAcT's 100 Hz.  Held parameters make the length of a "period" free
+ * (nothing is interpolated over it; the tube's sample rate stays the one the control rate and tube length derive,
+ * tube.c:596-612): with a slice of sampleRate / 1000 samples a write lands within a millisecond (shim/tract_tube.c does that).
+ * `tube_samples` >= 4, or 0 for the control period.  Only between utterances; TRM_EINVAL otherwise. */
+int  trm_stream_set_slice(trm_stream *stream, uint32_t tube_samples);
+uint32_t trm_stream_slice(const trm_stream *stream);
 int  trm_stream_kernel(const trm_stream *stream);          /* TRM_KERNEL_WIDE or TRM_KERNEL_QUAD (below) */
 int  trm_stream_mode(const trm_stream *stream);
 /* Exact number of samples per voice the next push of `nframes` frames (resp. the finish call) returns. */

@@ -19,7 +19,7 @@
  *    drains that buffer after every dataFill, so converter outputs are fp32-rounded;
  *    numberSamples and maximumSampleValue are read as the doubles/longs tube.c keeps.
  *
- * usage: tube_ref <case.bin> <out.bin> [tract]
+ * usage: tube_ref <case.bin> <out.bin> [tract [slice=N]]
  *   case.bin = trm_input_params | uint64 nframes | nframes*16 doubles
  *   out.bin  = see write_out() below
  *
@@ -81,8 +81,11 @@ static void drain(void)
 
 int main(int argc, char **argv)
 {
-    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s case.bin out.bin [tract]\n", argv[0]); return 2; }
-    const int tract = argc == 4 && !strcmp(argv[3], "tract");
+    if (argc < 3 || argc > 5) { fprintf(stderr, "usage: %s case.bin out.bin [tract [slice=N]]\n", argv[0]); return 2; }
+    const int tract = argc >= 4 && !strcmp(argv[3], "tract");
+    /* tract slice=N: every frame is held for N tube samples instead of a control period -- tube.c reads `current` every
+     * sample (tube.c:1121-1136), so this is its loop with the GUI's writes on a grid of N samples */
+    const int slice = (tract && argc == 5 && !strncmp(argv[4], "slice=", 6)) ? atoi(argv[4] + 6) : 0;
     FILE *fi = fopen(argv[1], "rb");
     if (!fi) { perror("case"); return 2; }
     trm_input_params p;
@@ -106,7 +109,8 @@ int main(int argc, char **argv)
     initCircBuff2();
     if (initializeSynthesizer() != 0) { fprintf(stderr, "initializeSynthesizer failed\n"); return 3; }
 
-    size_t ntube_cap = nframes > 1 ? (size_t)(nframes - 1) * (size_t)controlPeriod : 0, ntube = 0;
+    const int run = slice > 0 ? slice : controlPeriod;
+    size_t ntube_cap = nframes > 1 ? (size_t)(nframes - 1) * (size_t)run : 0, ntube = 0;
     double *tube = (double *)malloc((ntube_cap ? ntube_cap : 1) * sizeof(double));
     double tap_err = 0.0;
     double cur[16], delta[16];
@@ -118,7 +122,7 @@ int main(int argc, char **argv)
             delta[i] = (cur_in[i] - cur[i]) / (double)controlPeriod;
             if (tract) { cur[i] = cur_in[i]; delta[i] = 0.0; }   /* TRAcT: the set the GUI left in `current`, held */
         }
-        for (int j = 0; j < controlPeriod; j++) {
+        for (int j = 0; j < run; j++) {
             *getGlotPitch() = cur[0]; *getGlotVol() = cur[1]; *getAspVol() = cur[2]; *getFricVol() = cur[3];
             *getFricPos() = cur[4]; *getFricCF() = cur[5]; *getFricBW() = cur[6];
             for (int i = 0; i < 8; i++) *getRadius(i) = cur[7 + i];

@@ -611,8 +611,11 @@ static void tube_push(tube_t *t, double v)
  * (tube.c:1121-1136 converts current.* every sample) --, ten times the frication amplitude (tube.c:1371), the tube-rate
  * sample times 100 before the converter (tube.c:1177).  Pinned against the reference binary run in that order
  * (oracle/ref_driver.c `tract`, tests/golden/tract_mode_*.npz). */
+/* slice: TRAcT's loop order only -- the tube samples every frame is held for (0: a control period).  tube.c reads `current`
+ * every sample (tube.c:1121-1136), so parameters may change at any sample; a frame per `slice` samples is that loop with
+ * the changes on a grid of `slice` samples (trm_stream_set_slice). */
 static int synthesize_impl(const trm_input_params *p, const double *frames, size_t nframes,
-                           int keep_tube_samples, trm_oracle_result *out, int tract)
+                           int keep_tube_samples, trm_oracle_result *out, int tract, int32_t slice)
 {
     if (!p || !out || (nframes && !frames)) return TRM_EINVAL;
     memset(out, 0, sizeof *out);
@@ -625,7 +628,8 @@ static int synthesize_impl(const trm_input_params *p, const double *frames, size
     if (nframes > 0) {                                                          /* TRMTubeModel.m:274-277 */
         for (size_t f = 1; f < nframes; f++) {                                  /* :282-357 */
             set_control_rate(t, frames + 16 * f, frames + 16 * (tract ? f : f - 1));
-            for (int32_t j = 0; j < t->controlPeriod; j++) {
+            const int32_t run = (tract && slice > 0) ? slice : t->controlPeriod;
+            for (int32_t j = 0; j < run; j++) {
                 double f0 = trm_oracle_frequency(t->current[F_PITCH]);          /* :294-296 */
                 double ax = trm_oracle_amplitude(t->current[F_GLOTVOL]);
                 double ah1 = trm_oracle_amplitude(t->current[F_ASPVOL]);
@@ -691,13 +695,20 @@ static int synthesize_impl(const trm_input_params *p, const double *frames, size
 int trm_oracle_synthesize(const trm_input_params *p, const double *frames, size_t nframes,
                           int keep_tube_samples, trm_oracle_result *out)
 {
-    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 0);
+    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 0, 0);
 }
 
 int trm_oracle_synthesize_tract(const trm_input_params *p, const double *frames, size_t nframes,
                                 int keep_tube_samples, trm_oracle_result *out)
 {
-    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 1);
+    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 1, 0);
+}
+
+int trm_oracle_synthesize_tract_slices(const trm_input_params *p, const double *frames, size_t nframes, int32_t slice,
+                                       int keep_tube_samples, trm_oracle_result *out)
+{
+    if (slice < 1) return TRM_EINVAL;
+    return synthesize_impl(p, frames, nframes, keep_tube_samples, out, 1, slice);
 }
 
 /* bench.py's cpu_baseline leg: `count` voices of `nframes` frames each (frames = [voices][nframes][16] doubles),

@@ -41,6 +41,10 @@ int  trm_oracle_synthesize(const trm_input_params *params, const double *frames,
  * oracle/ref_driver.c `tract` ignores it. */
 int  trm_oracle_synthesize_tract(const trm_input_params *params, const double *frames, size_t nframes,
                                  int keep_tube_samples, trm_oracle_result *out);
+/* ... with every frame (from the second on) held for `slice` tube samples instead of a control period: tube.c's loop with
+ * parameter changes on a grid of `slice` samples (what trm_stream_set_slice streams). */
+int  trm_oracle_synthesize_tract_slices(const trm_input_params *params, const double *frames, size_t nframes, int32_t slice,
+                                        int keep_tube_samples, trm_oracle_result *out);
 void trm_oracle_result_free(trm_oracle_result *r);
 /* `count` voices in a row on the calling thread (bench.py's cpu_baseline: one call per thread, no Python in the loop) */
 int  trm_oracle_run_voices(const trm_input_params *params, const double *frames, size_t nframes, size_t nvoices,

@@ -8,14 +8,17 @@
  *   globals written through get*() pointers             the same globals (Controller.m:231 writes *getGlotPitch())
  *   initializeSynthesizer() (tube.c:580-680)            (re)creates the stream from the utterance-rate globals and
  *                                                       starts the synthesis thread once
- *   synthesize() thread (tube.c:1096-1190): one tube    synthesis thread: one control period per trm_stream_push of
+ *   synthesize() thread (tube.c:1096-1190): one tube    synthesis thread: one slice (~1 ms) per trm_stream_push of
  *   sample per iteration from `current`, no             the current parameter set, in TRM_STREAM_MODE_TRACT: the set is
- *   interpolation, x10 frication taps (:1371), x100     HELD for the period (a slider write steps at the next push, not
+ *   interpolation, x10 frication taps (:1371), x100     HELD for the slice (a slider write steps at the next push, not
  *   (:1177), dataFill -> dataEmpty -> circBuff2         glides), frication taps x10, output x100; PCM -> circBuff2
  *   getCircBuff2() (tube.c:3197-3230), circBuff2Count   the same blocking pop and counter (Controller.m:88-91)
  *
- * What remains different from tube.c: a slider write takes effect at the next control-period boundary (tube.c: at the
- * next sample; the boundary is <= 10 ms away at TRAcT's control rate of 100 Hz); the x100 gain is applied to the
+ * What remains different from tube.c: a slider write takes effect at the next SLICE boundary (tube.c: at the next sample).
+ * Round 4: the synthesis thread pushes one frame per slice of sampleRate / 1000 tube samples (trm_stream_set_slice; the
+ * parameters are held, so the length of a "period" is free), i.e. a write is heard within a millisecond where whole
+ * control periods made it up to 10 ms at TRAcT's 100 Hz.  The environment variable TRACT_SLICE_SAMPLES overrides the slice
+ * (0 = whole control periods, as rounds 2-3 pushed; tests use it for moves at known periods).  The x100 gain is applied to the
  * converter's output (tube.c: to its input; the converter is linear); the converter output is the library's fp32.
  * tests/test_tract_shim.py plays Controller.m's part and checks what comes out of circBuff2 against the REFERENCE's
  * tube.c run in its own loop order (tests/golden/tract_mode_*.npz) over whole utterances, slider moves included.
@@ -55,6 +58,7 @@ static int modulationDef = 1, waveformDef = 0;
 /* ---- derived (tube.c:596-612) */
 static double actualTubeLength;
 static int controlPeriod, sampleRate;
+static int sliceSamples;                       /* tube samples per push (0: a control period) */
 static double wavetable[512];
 
 /* ---- the circular buffer between the synthesis thread and the audio callback (tube.c:3141-3230) */
@@ -122,6 +126,7 @@ int *getWaveformDefault(void) { return &waveformDef; }
 int *getModulation(void) { return &modulation; }
 int *getModulationDefault(void) { return &modulationDef; }
 int *getControlPeriod(void) { return &controlPeriod; }
+int *getSliceSamples(void) { return &sliceSamples; }          /* (no tube.h counterpart: what a push stands for) */
 float *getControlRate(void) { return &controlRate; }
 int *getSampleRate(void) { return &sampleRate; }
 double *getWavetable(int i) { return &wavetable[i & 511]; }
@@ -202,6 +207,13 @@ int initializeSynthesizer(void)                 /* tube.c:580-680 */
     trm_stream *ns = NULL;
     int rc = trm_stream_create(&p, -1, 1, &ns);
     if (rc == 0) rc = trm_stream_set_mode(ns, TRM_STREAM_MODE_TRACT);          /* tube.c's own loop order */
+    {
+        /* tube.c reads `current` every sample (tube.c:1121-1136): push the parameter set every millisecond, not every period */
+        const char *e = getenv("TRACT_SLICE_SAMPLES");
+        sliceSamples = e ? atoi(e) : (int)lrint(sampleRate / 1000.0);
+        if (sliceSamples != 0 && sliceSamples < 4) sliceSamples = 4;
+        if (rc == 0) rc = trm_stream_set_slice(ns, (uint32_t)sliceSamples);
+    }
     if (rc == 0) {
         if (stream) trm_stream_destroy(stream);
         stream = ns;

@@ -184,6 +184,24 @@ def tract_mode_cases():
     return out
 
 
+TRACT_SLICE = 21                # tube samples per frame of the slice cases: 1.02 ms at the shim tube's 20 600 Hz (control period 206)
+
+
+def tract_slice_cases():
+    """name -> (params, frames, slice): tube.c in its own loop order with the parameters changing on a grid of TRACT_SLICE
+    samples -- a slider written in the MIDDLE of a control period, which whole-period pushes could only apply up to 10 ms
+    late (trm_stream_set_slice; oracle/ref_driver.c `tract slice=N`).  600 slices (0.61 s): the vowel; at slice 233
+    (sample 4893 = control period 23.75) radius 7 steps to 0.4; at slice 351 frication, aspiration and a constriction come
+    on; at slice 437 the frication moves.  (The moves lie behind the first 8192 outputs: tests/tract_shim_driver.c places a
+    slider write by filling TRAcT's circular buffer first.)"""
+    fr = static_frames(TRACT_SHIM_FRAME, 601)
+    fr[233:, 7 + 6] = float(np.float32(0.4))
+    fr[351:, [2, 3, 4, 5, 6]] = np.float32([12.0, 42.5, 5.3, 3500.0, 1800.0]).astype(np.float64)
+    fr[351:, 7 + 5] = float(np.float32(0.2))
+    fr[437:, [3, 4, 5]] = np.float32([55.0, 6.75, 2500.0]).astype(np.float64)
+    return {"tract_mode_slice_step": (tract_shim_params(), fr, TRACT_SLICE)}
+
+
 # pitch, glotVol, aspVol, fricVol, fricPos, fricCF, fricBW, r1..r8, velum
 TRACT_FRIC_FRAME = [-2.0, 54.0, 20.0, 45.0, 5.4, 4500.0, 2000.0, 0.8, 1.2, 1.5, 1.7, 1.4, 0.25, 0.9, 1.2, 0.0]
 TRACT_FRIC_ON, TRACT_FRIC_MOVE = 40, 85

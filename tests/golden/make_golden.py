@@ -5,7 +5,9 @@ Runs oracle/_ref/tube_ref (Applications/TRAcT/tube.c compiled in place from /roo
 by oracle/Makefile, driven by oracle/ref_driver.c) on every case of tests/cases.golden_cases()
 and freezes what the reference computed: tube-rate doubles, converter output (fp32, as tube.c's
 dataEmpty emits it), numberSamples, maximumSampleValue, FIR taps, derived constants.
-cases.tract_mode_cases() run through the same binary in TRAcT's own loop order (ref_driver.c `tract`).
+cases.tract_mode_cases() run through the same binary in TRAcT's own loop order (ref_driver.c `tract`),
+cases.tract_slice_cases() in that order with the parameters changing on a grid of samples (`tract slice=N`).
+A list of case names on the command line regenerates only those.
 Only runs where /root/reference exists; the .npz files are the committed fixtures.
 
     make -C oracle && python tests/golden/make_golden.py
@@ -27,11 +29,15 @@ def main():
     if not O.have_ref():
         sys.exit("oracle/_ref/tube_ref missing: run `make -C oracle` where /root/reference exists")
     h_saved = False
-    todo = [(n, c, False) for n, c in cases.golden_cases().items()] + [(n, c, True) for n, c in cases.tract_mode_cases().items()]
-    for name, (pd, frames), tract in todo:
+    todo = [(n, c + (0,), False) for n, c in cases.golden_cases().items()] + [(n, c + (0,), True) for n, c in cases.tract_mode_cases().items()]
+    todo += [(n, c, True) for n, c in cases.tract_slice_cases().items()]       # (round 4: parameters on a grid of `slice` samples)
+    only = sys.argv[1:]
+    for name, (pd, frames, slc), tract in todo:
+        if only and name not in only:
+            continue
         p = O.InputParams.from_dict(pd)
         with tempfile.TemporaryDirectory() as d:
-            r = O.run_ref(p, frames, d, tract=tract)
+            r = O.run_ref(p, frames, d, tract=tract, slice=slc)
         np.savez_compressed(
             os.path.join(HERE, name + ".npz"),
             params_json=np.array(json.dumps(pd)),
@@ -44,6 +50,7 @@ def main():
             derived=np.array([r["controlPeriod"], r["sampleRate"], r["padSize"], r["firTaps"],
                               r["timeRegisterIncrement"], r["phaseIncrement"]], dtype=np.int64),
             tap_err=np.float64(r["tap_err"]),
+            slice=np.int64(slc),
         )
         if not h_saved:
             np.savez_compressed(os.path.join(HERE, "src_tables.npz"), h=r["h"], deltaH=r["deltaH"])

@@ -12,6 +12,8 @@ CASE_NAMES = ["tract_vowel_1s", "monet_vowel_44k", "monet_vowel_22k", "gnuspeech
               "female_15cm_stereo"]
 # the reference's tube.c stepped in TRAcT's OWN loop order (oracle/ref_driver.c `tract`)
 TRACT_CASE_NAMES = ["tract_mode_ee_step", "tract_mode_fricative", "tract_mode_fric_step"]
+# ... and with its parameters changing on a grid of `slice` samples (`tract slice=N`; trm_stream_set_slice)
+TRACT_SLICE_CASE_NAMES = ["tract_mode_slice_step"]
 
 
 def load(name):
@@ -22,4 +24,5 @@ def load(name):
     g["params"] = O.InputParams.from_dict(pd)
     g["numberSamples"] = int(g["numberSamples"])
     g["maximumSampleValue"] = float(g["maximumSampleValue"])
+    g["slice"] = int(g["slice"]) if "slice" in g else 0
     return g

@@ -80,6 +80,8 @@ def lib():
         L.trm_oracle_synthesize.restype = C.c_int
         L.trm_oracle_synthesize_tract.argtypes = L.trm_oracle_synthesize.argtypes
         L.trm_oracle_synthesize_tract.restype = C.c_int
+        L.trm_oracle_synthesize_tract_slices.argtypes = L.trm_oracle_synthesize.argtypes[:3] + [C.c_int32] + L.trm_oracle_synthesize.argtypes[3:]
+        L.trm_oracle_synthesize_tract_slices.restype = C.c_int
         L.trm_oracle_result_free.argtypes = [C.POINTER(_Result)]
         L.trm_oracle_run_voices.argtypes = [C.POINTER(InputParams), C.POINTER(C.c_double), C.c_size_t, C.c_size_t,
                                             C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
@@ -113,14 +115,17 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def synthesize(params, frames, keep_tube=False, tract=False):
+def synthesize(params, frames, keep_tube=False, tract=False, slice=0):
     """Run the oracle.  frames: [n,16] float64.  Returns dict(samples, numberSamples,
     maximumSampleValue, tubeSamples, derived).  tract: in the loop order of Applications/TRAcT/tube.c (frame f >= 1 held
     for control period f, x10 frication taps, x100 before the converter; oracle/trm_oracle.h)."""
     frames = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 16)
     res = _Result()
-    fn = lib().trm_oracle_synthesize_tract if tract else lib().trm_oracle_synthesize
-    rc = fn(C.byref(params), _dptr(frames), frames.shape[0], int(keep_tube), C.byref(res))
+    if tract and slice:          # every frame held for `slice` tube samples (trm_oracle.h)
+        rc = lib().trm_oracle_synthesize_tract_slices(C.byref(params), _dptr(frames), frames.shape[0], int(slice), int(keep_tube), C.byref(res))
+    else:
+        fn = lib().trm_oracle_synthesize_tract if tract else lib().trm_oracle_synthesize
+        rc = fn(C.byref(params), _dptr(frames), frames.shape[0], int(keep_tube), C.byref(res))
     if rc != 0:
         raise RuntimeError("trm_oracle_synthesize rc=%d" % rc)
     n = res.numberSamples
@@ -196,7 +201,7 @@ def have_ref():
     return os.path.exists(REF_BIN)
 
 
-def run_ref(params, frames, workdir, tract=False):
+def run_ref(params, frames, workdir, tract=False, slice=0):
     """Run oracle/_ref/tube_ref (the reference's own tube.c behind oracle/ref_driver.c); tract: in TRAcT's own
     sample-loop order (tube.c:1096-1190: held parameters, x10 taps, x100 gain) instead of Frameworks/Tube's."""
     frames = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 16)
@@ -206,7 +211,7 @@ def run_ref(params, frames, workdir, tract=False):
         f.write(bytes(params))
         f.write(np.uint64(frames.shape[0]).tobytes())
         f.write(frames.tobytes())
-    subprocess.check_call([REF_BIN, case, outp] + (["tract"] if tract else []))
+    subprocess.check_call([REF_BIN, case, outp] + (["tract"] if tract else []) + (["slice=%d" % slice] if tract and slice else []))
     raw = open(outp, "rb").read()
     o = 0
 

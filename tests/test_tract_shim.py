@@ -26,9 +26,14 @@ def driver(tmp_path_factory):
     return exe
 
 
-def run_driver(exe, tmp_path, total, *events):
+def run_driver(exe, tmp_path, total, *events, slice_samples=0):
+    """slice_samples: TRACT_SLICE_SAMPLES for the shim -- 0 = one control period per push (moves land at period boundaries:
+    what the period-stepped goldens need), None = the shim's default (a millisecond)."""
     out = str(tmp_path / "heard.f32")
     env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.pop("TRACT_SLICE_SAMPLES", None)
+    if slice_samples is not None:
+        env["TRACT_SLICE_SAMPLES"] = str(slice_samples)
     r = subprocess.run([exe, out, str(total)] + list(events), capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stderr
     return np.fromfile(out, dtype=np.float32), r
@@ -40,8 +45,9 @@ def nrms(x, ref, mx):
 
 
 def outputs_after(periods, gold):
-    """Converter outputs the stream has returned after `periods` control periods (trm_stream_samples_for_push's sum)."""
-    cp, inc = int(gold["derived"][0]), int(gold["derived"][4])
+    """Converter outputs the stream has returned after `periods` pushes (control periods, or the golden's slices:
+    trm_stream_samples_for_push's sum)."""
+    cp, inc = gold["slice"] or int(gold["derived"][0]), int(gold["derived"][4])
     n = periods * cp
     return 0 if n == 0 else ((n << 16) - 1) // inc + 1
 
@@ -90,6 +96,30 @@ def test_tract_shim_against_the_reference_in_tract_order(driver, tmp_path, name)
     per = int(round(44100.0 / 100.0))
     worst = max(nrms(heard[i:i + per], want[i:i + per], mx) for i in range(0, total - per, per))
     assert worst <= 1e-5, "%s: worst control period %.3e" % (name, worst)
+
+
+def test_tract_shim_slider_write_lands_within_a_millisecond(driver, tmp_path):
+    """The shim as it ships pushes a frame per millisecond (21 tube samples at its 20 600 Hz): slider writes in the MIDDLE of
+    a control period -- radius 7 at sample 4893 (period 23.75), a fricative at slice 351, a move at 437 -- are heard from the
+    next slice on, like tube.c hears them from the next sample on.  Against the REFERENCE's tube.c run with its parameters
+    changing on that grid (tests/golden/tract_mode_slice_step.npz, oracle/ref_driver.c `tract slice=21`): the whole
+    utterance and every single millisecond of it."""
+    gold = golden_io.load("tract_mode_slice_step")
+    assert gold["slice"] == cases.TRACT_SLICE and gold["params_dict"] == cases.tract_shim_params()
+    want, mx = gold["samples_f32"].astype(np.float64), gold["maximumSampleValue"]
+    total = outputs_after(len(gold["frames"]) - 1, gold) - 64
+    ev = events_from_frames(gold)
+    assert len(ev) == 3
+    heard, r = run_driver(driver, tmp_path, total, *ev, slice_samples=None)
+    assert "slice %d" % cases.TRACT_SLICE in r.stdout
+    assert heard.size == total and np.all(np.isfinite(heard))
+    assert nrms(heard, want[:total], mx) <= 1e-5
+    per = 45                                # a slice's outputs
+    worst = max(nrms(heard[i:i + per], want[i:i + per], mx) for i in range(0, total - per, per))
+    assert worst <= 1e-5, "worst millisecond %.3e" % worst
+    # with whole control periods per push the same writes come up to 10 ms late: far outside the tolerance
+    late, _ = run_driver(driver, tmp_path, total, *ev, slice_samples=0)
+    assert nrms(late, want[:total], mx) > 1e-3
 
 
 def test_tract_shim_equals_the_python_stream(driver, tmp_path):

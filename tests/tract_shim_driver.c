@@ -23,6 +23,7 @@ double *getGlotPitch(void), *getGlotVol(void), *getAspVol(void), *getFricVol(voi
 double *getActualTubeLength(void);
 int *getControlPeriod(void);
 int *getSampleRate(void);
+int *getSliceSamples(void);
 void shutdownSynthesizer(void);
 extern int circBuff2Count;
 
@@ -74,7 +75,8 @@ int main(int argc, char **argv)
     if (!f) return 3;
     fwrite(buf, sizeof(float), (size_t)total, f);
     fclose(f);
-    printf("controlPeriod %d sampleRate %d actualTubeLength %.6f\n", *getControlPeriod(), *getSampleRate(), *getActualTubeLength());
+    printf("controlPeriod %d sampleRate %d actualTubeLength %.6f slice %d\n", *getControlPeriod(), *getSampleRate(), *getActualTubeLength(),
+           *getSliceSamples());
     shutdownSynthesizer();
     return 0;
 }
