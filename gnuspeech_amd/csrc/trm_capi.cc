@@ -710,6 +710,11 @@ struct trm_stream {
     bool wide = false;                // trm_kernels.hip's streaming instance (one voice per lane) instead of trm_quad.hip's
     uint64_t nBase = 0, kBase = 0;    // tube samples synthesized / converter outputs emitted so far
     int32_t controlPeriod0 = 0;       // the control period the parameters derive (trm_stream_set_slice(.., 0) returns to it)
+    // Chunks of one stream are ordered on the device whichever HIP stream each call names (host entries: the object's own,
+    // device entries: the caller's): every chunk ends with this event and a chunk on another stream waits for it first.
+    hipEvent_t chunkDone = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool haveChunk = false;
 };
 
 int trm_stream_create(const trm_input_params *params, int device, size_t nvoices, trm_stream **out)
@@ -764,6 +769,7 @@ void trm_stream_destroy(trm_stream *s)
     if (!s) return;
     if (s->b) (void)hipSetDevice(s->b->device);
     trm_batch *b = s->b;
+    if (s->chunkDone) (void)hipEventDestroy(s->chunkDone);
     delete s;               // device buffers first (the batch owns the stream they were used on)
     trm_batch_destroy(b);
 }
@@ -832,8 +838,24 @@ size_t trm_stream_samples_for_finish(const trm_stream *s)
 
 // One chunk on the device: control periods from the stream's last frame through the pushed frames `d_pushed` (device,
 // [nvoices][nframes][16]), or the converter's flush; PCM to d_out (device, voice v at d_out + v * out_pitch).  Everything
-// is work on `st`; nothing here waits for the device.
+// is work on `st`, ordered behind the chunk before it (which may have run on another stream: an event).  The host is made
+// to wait only when the chunk's shape changes (the index arrays are re-uploaded) or the noise sequence has to grow.
+static int stream_chunk_device_impl(trm_stream *s, const float *d_pushed, size_t nframes, bool flush, float *d_out, size_t out_pitch,
+                                    uint32_t *nout, hipStream_t st);
 static int stream_chunk_device(trm_stream *s, const float *d_pushed, size_t nframes, bool flush, float *d_out, size_t out_pitch,
+                               uint32_t *nout, hipStream_t st)
+{
+    if (s->haveChunk && st != s->lastStream) HIP_TRY(hipStreamWaitEvent(st, s->chunkDone, 0));
+    int rc = stream_chunk_device_impl(s, d_pushed, nframes, flush, d_out, out_pitch, nout, st);
+    if (rc) return rc;
+    if (!s->chunkDone) HIP_TRY(hipEventCreateWithFlags(&s->chunkDone, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->chunkDone, st));
+    s->lastStream = st;
+    s->haveChunk = true;
+    return TRM_OK;
+}
+
+static int stream_chunk_device_impl(trm_stream *s, const float *d_pushed, size_t nframes, bool flush, float *d_out, size_t out_pitch,
                                uint32_t *nout, hipStream_t st)
 {
     trm_batch *b = s->b;

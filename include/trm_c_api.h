@@ -353,7 +353,9 @@ int  trm_stream_finish(trm_stream *stream, float *out, size_t out_pitch, uint32_
  * and nothing crosses PCIe -- what a server that mixes, encodes or plays the voices on the device uses, and what the
  * number of concurrent real-time voices is measured with (tools/realtime_voices.py): PCM returned to the host costs
  * 88-176 KB per voice-second, so PCIe (not the kernel) bounds a host-returning stream at ~0.3-0.6 M voices per GPU.
- * *nout is known on return (it depends on the frame count only).  Host- and device-buffer calls of one stream may be mixed.
+ * *nout is known on return (it depends on the frame count only).  Host- and device-buffer calls of one stream may be mixed,
+ * and successive calls may name different HIP streams: a chunk is ordered behind the one before it on the device (an event).
+ * The host waits only when a chunk's shape (frames per push, out_pitch) changes or the noise sequence has to grow.
  * (The kernels store PCM in 128-byte pieces: a 128-byte aligned d_out and an out_pitch that is a multiple of 32 floats keep every
  * piece within one cache line.) */
 int  trm_stream_push_device(trm_stream *stream, const float *d_frames, size_t nframes, float *d_out, size_t out_pitch,

@@ -273,6 +273,63 @@ def test_device_buffer_entries_equal_the_host_entries(g, rate, mode):
     assert float(big[:, pos:].abs().max()) == 0.0                                      # nothing written past the samples
 
 
+def test_chunks_on_different_hip_streams_are_ordered(g):
+    """successive calls of one stream may name different HIP streams (host entries run on the object's own,
+    device entries on the caller's): every chunk is ordered behind the one before it by an event.  Many voices, chunks
+    alternating between two NON-BLOCKING torch streams and the host entry, no synchronisation in between: the samples of the
+    all-host sequence, bit for bit."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    V, n = 4096, 41
+    fr = np.tile(cases.config3_frames(64, nframes=n, seed=7).astype(np.float32), (V // 64, 1, 1))
+    chunks = [1, 10, 10, 10, 10]
+    s = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=V)
+    parts, at = [], 0
+    for c in chunks:
+        parts.append(s.push(fr[:, at:at + c])[0]); at += c
+    parts.append(s.finish()[0])
+    want = np.concatenate(parts, axis=1)
+    d = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=V)
+    dev = torch.device("cuda", 0)
+    frd = torch.from_numpy(fr).to(dev)
+    big = torch.zeros((V, want.shape[1] + 32), dtype=torch.float32, device=dev)
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)      # non-blocking: no implicit order with anything
+    torch.cuda.synchronize()
+    at = pos = 0
+    for i, c in enumerate(chunks):
+        piece = frd[:, at:at + c].contiguous()
+        torch.cuda.synchronize() if i == 0 else None       # (the slices above were made on the default stream)
+        with torch.cuda.stream(sa if i % 2 == 0 else sb):
+            piece.record_stream(torch.cuda.current_stream())
+            _, m = d.push_device(piece, out=big[:, pos:])
+        at += c
+        pos += m
+    with torch.cuda.stream(sa):
+        _, m = d.finish_device(out=big[:, pos:])
+    pos += m
+    torch.cuda.synchronize()
+    assert pos == want.shape[1]
+    assert np.array_equal(big[:, :pos].cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_tract_order_stream_of_more_voices_than_a_grid_dimension(g):
+    """TRAcT order's x100 (trm_gain_kernel) once put the voice index in gridDim.y (limit 65 535); a stream of
+    70 000 voices in that order must come back, voices at both ends equal to the same tracks in a small stream."""
+    pd = cases.tract_shim_params()
+    base = cases.config3_frames(8, nframes=4, seed=3).astype(np.float32)
+    V = 70000
+    fr = np.tile(base, (V // 8, 1, 1))
+    big = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=V, mode="tract")
+    small = g.TRMStream(g.TRMInputParameters.from_dict(pd), nvoices=8, mode="tract")
+    if big.kernel != small.kernel:          # (same arithmetic either way; same kernel form = same bits)
+        pytest.skip("forms differ")
+    a = np.concatenate([big.push(fr)[0], big.finish()[0]], axis=1)
+    b = np.concatenate([small.push(base)[0], small.finish()[0]], axis=1)
+    assert np.all(np.isfinite(a)) and float(np.abs(a).max()) > 0.0
+    for v in (0, 7, 65535, 65536, V - 1):
+        assert np.array_equal(a[v], b[v % 8]), v
+
+
 def test_large_wide_stream_across_launch_slices(g, stream_form):
     """A stream of more voices than one launch slice of the one-voice-per-lane kernel holds (65 536): its per-workgroup state
     blocks, the sliced launches and the device-buffer entries together -- identical tracks give identical bits in whichever
