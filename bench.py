@@ -290,23 +290,43 @@ def stream_record(N=1048576, chunks=10, chunk_frames=25):
 def end_to_end_record(g, pd, caller_order, reps=3):
     """configs[3] as SURVEY 8(d) defines "end to end through TRM": the C-ABI host entry -- H2D of the frames, the kernels, the
     converter, per-voice maxima, D2H of the PCM -- on the batch in the CALLER's order (the library sorts by length itself),
-    into an output buffer the caller keeps between calls; fp32 PCM and the containers' int16."""
+    called the way a C caller calls it: one packed [sum n][16] fp32 frame array + offsets in, a kept output buffer out (what
+    gnuspeech_amd.TRMBatch does before it gets here -- packing 1024 numpy arrays -- is the Python mirror's cost, timed
+    separately as `python_mirror_ms`); fp32 PCM and the containers' int16."""
+    import ctypes as C
     import numpy as np
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    L = g.lib()
+    V = len(caller_order)
+    nfr = np.array([len(u) for u in caller_order], dtype=np.uint32)
+    foff = np.concatenate([[0], np.cumsum(nfr[:-1], dtype=np.uint64)]).astype(np.uint64)
+    frames = np.ascontiguousarray(np.concatenate([np.asarray(u, dtype=np.float32) for u in caller_order]))
+    nout = np.array([b.samples_for_frames(int(n)) for n in nfr], dtype=np.uint64)
+    ooff = np.concatenate([[0], np.cumsum(nout[:-1], dtype=np.uint64)]).astype(np.uint64)
+    total = int(nout.sum())
+    ns, mx = np.zeros(V, dtype=np.uint32), np.zeros(V, dtype=np.float32)
     out = {}
-    for name, fn in (("fp32", b.synthesize), ("int16", b.synthesize_int16)):
-        fn(caller_order, reuse_output=True)
+    for name, entry, dtype, extra in (("fp32", L.trm_batch_synthesize_host, np.float32, ()), ("int16", L.trm_batch_synthesize_host_int16, np.int16, (0,))):
+        buf = np.ones(total, dtype=dtype)                 # every page touched: the caller keeps this buffer between calls
         ts = []
-        for _ in range(reps):
+        for _ in range(reps + 1):
             t0 = time.perf_counter()
-            pcm, ns, mx = fn(caller_order, reuse_output=True)
+            rc = entry(b._h, V, frames.ctypes.data, foff.ctypes.data, nfr.ctypes.data, buf.ctypes.data, ooff.ctypes.data, ns.ctypes.data,
+                       mx.ctypes.data, *extra)
             ts.append(time.perf_counter() - t0)
-        total = int(np.asarray(ns, dtype=np.int64).sum())
-        out[name] = {"ms": min(ts) * 1e3, "samples_per_s": total / min(ts), "output_samples": total}
-        pcm = None
+            assert rc == 0 and int(ns.sum()) == total
+        out[name] = {"ms": min(ts[1:]) * 1e3, "samples_per_s": total / min(ts[1:]), "output_samples": total,
+                     "bytes_over_pcie": int(frames.nbytes + buf.nbytes)}
+        buf = None
+    t0 = time.perf_counter()
+    b.synthesize(caller_order, reuse_output=True)
+    t0 = time.perf_counter()
+    b.synthesize(caller_order, reuse_output=True)
+    out["python_mirror_ms"] = (time.perf_counter() - t0) * 1e3
     out["time_split"] = list(b.last_time_split)
-    out["how"] = ("trm_batch_synthesize_host / _host_int16 through gnuspeech_amd.TRMBatch (packing the 1024 per-voice arrays + H2D + kernels + "
-                  "D2H into a kept buffer), best of %d" % reps)
+    out["how"] = ("trm_batch_synthesize_host / _host_int16 on a packed frame array (%d voices in the caller's order, %.0f MB of frames in, the PCM "
+                  "into a buffer the caller keeps), best of %d; python_mirror_ms = gnuspeech_amd.TRMBatch.synthesize on the list of per-voice "
+                  "arrays (packing included)" % (V, frames.nbytes / 1e6, reps))
     return out
 
 
@@ -440,7 +460,7 @@ def main():
     form = b.last_kernel + ("/split" if split[0] else "")
     traffic, valu, traffic_note = lookup_traffic(voices, nframes, workload, form, avg_launch_s)
     kernel_name = {"wide": "trm_tube_kernel<0>", "quad": "trm_tube_kernel_q", "oct": "trm_tube_kernel_o",
-                   "wide/split": "trm_tube_kernel<2> (+ trm_phase_kernel)"}[form]
+                   "wide/split": "trm_tube_kernel<2> (+ trm_phase_period_kernel, trm_phase_segment_kernel)"}[form]
     out = {
         "metric": "audio samples/s (whole node) + concurrent real-time tube voices",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
