@@ -404,9 +404,9 @@ static int ensure_noise(trm_batch *b, uint32_t need, hipStream_t stream)
 // :796-829), the end filters, the throat and the frication band-pass are stable one- and two-pole sections, the FIR and
 // the converter are feed-forward, the noise sequence is addressed by its index and the oscillator position is an exact
 // prefix sum.  A tube started from rest therefore agrees with the uninterrupted one after a warm-up: the difference
-// decays like the slowest pole, pole^n.  (Measured against the oracle, tools/timesplit_study.py: with damping^W = 1e-6
+// decays like the slowest pole, pole^n.  (Measured against the oracle, tools/timesplit_study.py: with damping^W = 1e-5
 // even a voice with mouth and velum closed -- nothing but the damping factor takes energy out -- is back at the
-// unsplit path's own error, 2e-6 worst sample; open voices get there in half the time.)  An utterance can so be cut in
+// unsplit path's own error, 2e-6 worst sample; open voices get there in two thirds of the time.)  An utterance can so be cut in
 // time and its pieces run side by side: what bounds a small or ragged batch is the serial chain of its longest voice.
 namespace {
 struct SplitPlan {
@@ -414,7 +414,12 @@ struct SplitPlan {
     uint32_t warm = 0;            // warm-up control periods
     float bwFloor = 0.0f;         // frication bandwidths below this need a longer warm-up: the launch falls back (device-side)
 };
-constexpr double kSplitLogEps = -13.815510557964274;      // ln(1e-6): what is left of the state the warm-up starts without
+// ln(1e-5): what is left of the state the warm-up starts without.  Measured (tools/timesplit_study.py, 180 random and
+// adversarial voices on the host model): with this warm-up (30 control periods at Monet's defaults) the split path differs from
+// the whole-utterance path by its fp32 noise floor -- worst single sample 8.5e-6 of the maximum, RMS 1.5e-6 -- exactly as with
+// 1.1x and 1.2x the warm-up; with 0.9x it starts to show (1.1e-5 / 1.6e-6).  The output error is ~0.15 of the bound for the
+// voice that forgets slowest (mouth and velum closed).
+constexpr double kSplitLogEps = -11.512925464970229;
 }  // namespace
 
 // warm-up (tube samples) after which a tube started from rest has forgotten that it was; 0 = never (a pole on the unit circle)
@@ -504,7 +509,7 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
     pl.warm = warm;
     {
         // the frication band-pass (TRMFilters.m:9-29) has poles of radius sqrt(2 beta), 2 beta = (1 - t) / (1 + t),
-        // t = tan(pi BW / SR): the bandwidth at which the warm-up leaves 1e-6 of its memory
+        // t = tan(pi BW / SR): the bandwidth at which the warm-up leaves 1e-5 of its memory
         const double r2 = exp(2.0 * kSplitLogEps / (double)(warm * CP - 64u));
         const double t = (1.0 - r2) / (1.0 + r2);
         pl.bwFloor = (float)((double)b->d.sampleRate * atan(t) / 3.14159265358979323846);

@@ -386,8 +386,8 @@ int  trm_batch_last_kernel(const trm_batch *batch);
  * once per sample (:216), the end filters, throat and frication band-pass are stable filters, the oscillator FIR and the
  * converter are feed-forward, the noise is a fixed sequence and the oscillator position an exact prefix sum.  A time-split
  * launch cuts every utterance into segments of `periods` control periods and runs them side by side, each from rest a
- * warm-up ahead of its first period; the warm-up is chosen by the library so that 1e-6 of the forgotten state is left
- * (damping^W <= 1e-6: 35 control periods at Monet's defaults; measured against the oracle in tools/timesplit_study.py
+ * warm-up ahead of its first period; the warm-up is chosen by the library so that 1e-5 of the forgotten state is left
+ * (damping^W <= 1e-5: 30 control periods at Monet's defaults; measured against the oracle in tools/timesplit_study.py
  * and by the parity tests at the one tolerance, 1e-5).  numberSamples and the sample positions are exact as always.
  *   TRM_TIME_SPLIT_AUTO (default)  the library splits when its launch-time model says so (a form set by name with
  *                                  trm_batch_set_kernel / TRM_TUBE_KERNEL runs whole utterances);

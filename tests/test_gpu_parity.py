@@ -915,7 +915,7 @@ def test_full_size_configs4_per_gpu_batch(g, split):
     b.synthesize_device(st)
     torch.cuda.synchronize()
     if split == "auto":
-        assert b.last_kernel == "wide" and b.last_time_split == (54, 36)        # 90 + 3 x 54 periods: four segments of 128 workgroups
+        assert b.last_kernel == "wide" and b.last_time_split == (55, 30)        # 85 + 3 x 55 periods: four segments of 128 workgroups
     else:
         assert b.last_kernel == "quad" and b.last_time_split == (0, 0)
     ns = st["number_samples"].cpu().numpy()

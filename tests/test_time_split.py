@@ -45,13 +45,13 @@ def emul():
 
 
 def warm_periods(pd, control_period):
-    """The library's rule (trm_capi.cc split_warm_samples): the slowest pole to the power W = 1e-6, + 64 samples."""
+    """The library's rule (trm_capi.cc split_warm_samples): the slowest pole to the power W = 1e-5, + 64 samples."""
     import math
     rate = control_period * pd["controlRate"]
     nyq = rate / 2.0
     poles = [1.0 - pd["lossFactor"] / 100.0, abs((nyq - pd["mouthCoef"]) / nyq), abs((nyq - pd["noseCoef"]) / nyq),
              abs(1.0 - 2.0 * pd["throatCutoff"] / rate)]
-    w = math.ceil(math.log(1e-6) / math.log(max(poles))) + 64
+    w = math.ceil(math.log(1e-5) / math.log(max(poles))) + 64
     return (w + control_period - 1) // control_period
 
 
@@ -86,7 +86,7 @@ def test_host_model_closed_tract_needs_the_full_warm_up(emul):
     fr = cases.static_frames(MV_CLOSED, 401)
     o = O.synthesize(p, np.asarray(fr, dtype=np.float32).astype(np.float64))
     warm = warm_periods(pd, int(o["derived"]["controlPeriod"]))
-    assert warm == 36
+    assert warm == 30
     whole, _ = _emul_split(emul, p, fr, 1 << 30, 0)
     good, _ = _emul_split(emul, p, fr, 50, warm)
     short, _ = _emul_split(emul, p, fr, 50, warm // 3)
@@ -148,7 +148,7 @@ def test_split_ragged_batch_against_oracle(g):
     voices += [np.zeros((0, 16)), rows[5:6].copy(), rows[100:102].copy(), cases.static_frames(MV_CLOSED, 140)]
     b = _batch(g, pd, 25)
     pcm, ns, mx = b.synthesize(voices)
-    assert b.last_time_split == (25, 36)
+    assert b.last_time_split == (25, 30)
     op = O.InputParams.from_dict(pd)
     worst = 0.0
     for v, fr in enumerate(voices):
@@ -237,7 +237,7 @@ def test_narrow_frication_band_falls_back_to_whole_utterances(g):
     ref, nsr, mxr = whole.synthesize(narrow)
     b = _batch(g, pd, 30)
     pcm, ns, mx = b.synthesize(narrow)
-    assert b.last_time_split == (30, 36)                        # (set up as a split launch; the device decided otherwise)
+    assert b.last_time_split == (30, 30)                        # (set up as a split launch; the device decided otherwise)
     assert np.array_equal(ns, nsr) and np.array_equal(mx, mxr)
     for v in range(66):
         assert np.array_equal(pcm[v], ref[v]), v
@@ -258,7 +258,7 @@ def test_auto_splits_the_sentence_batch_and_leaves_named_forms_alone(g):
     b = _batch(g, pd, "auto")
     pcm, ns, mx = b.synthesize(utt)
     sp, warm = b.last_time_split
-    assert sp > 0 and warm == 36 and b.last_kernel == "wide"
+    assert sp > 0 and warm == 30 and b.last_kernel == "wide"
     op = O.InputParams.from_dict(pd)
     lens = np.array([len(u) for u in utt])
     order = np.argsort(lens)

@@ -4,7 +4,10 @@
 Runs the host model of the segmented path (tests/_emul: trm_emul_synthesize_split -- every segment after the first starts
 from REST `warm` control periods early; oscillator position and noise index are exact) against the oracle for a set of
 voices and warm-up lengths and prints the normalised RMS over the whole utterance and the worst normalised error of a
-single sample.  usage: timesplit_study.py [seg_periods]"""
+single sample.  usage: timesplit_study.py [seg_periods]
+       timesplit_study.py --random N     N random / adversarial voices (closed mouth + velum, narrow constrictions, loud-then-quiet
+                                         tracks) at Monet's defaults: the worst difference of the split path from the WHOLE-utterance
+                                         path of the same arithmetic, by warm-up length (what the library's 1e-5 rule was chosen on)"""
 import ctypes as C
 import math
 import os
@@ -59,7 +62,51 @@ def voices():
     return out
 
 
+def random_study(N):
+    rng = np.random.default_rng(1)
+    pd = cases.monet_default_params(44100.0)
+    p = O.InputParams.from_dict(pd)
+    warms = (24, 27, 30, 33, 36)
+    worst = {w: (0.0, None) for w in warms}
+    rms_w = {w: 0.0 for w in warms}
+    used = 0
+    for it in range(N):
+        n = 260
+        knots = max(2, n // int(rng.integers(4, 40)))
+        t = np.linspace(0, knots - 1, n)
+
+        def track(lo, hi):
+            return np.interp(t, np.arange(knots), rng.uniform(lo, hi, knots))
+        kind = it % 4
+        fr = np.stack([track(-10, 6), track(30, 60), track(0, 20), track(0, 40), track(0, 7), track(500, 5000), track(250, 2500)] +
+                      [track(0.05, 2.5) for _ in range(8)] + [track(0.0, 1.2)], axis=1)
+        if kind == 1:       # mouth closed, velum (nearly) closed
+            fr[:, 14] = 0.01
+            fr[:, 15] = rng.choice([0.0, 0.02, 0.1])
+        if kind == 2:       # static, one narrow constriction
+            fr[:] = fr[0]
+            fr[:, 7 + int(rng.integers(0, 8))] = 0.02
+        if kind == 3:       # loud, then quiet: what the warm-up forgets is large against what follows
+            fr[:, 1] = np.concatenate([np.full(120, 60.0), np.linspace(60, 20, 140)])
+        whole = split(p, fr, 1 << 30, 0).astype(np.float64)
+        mx = np.abs(whole).max()
+        if mx < 1e-3:       # nearly silent voices: fp32 noise (the parity tools match them on an absolute floor)
+            continue
+        used += 1
+        for w in warms:
+            y = split(p, fr, 40, w).astype(np.float64)
+            d = np.abs(y - whole).max() / mx
+            rms_w[w] = max(rms_w[w], math.sqrt(np.mean(((y - whole) / mx) ** 2)))
+            if d > worst[w][0]:
+                worst[w] = (d, (it, kind))
+    print("%d voices (%d not nearly silent), segments of 40 control periods, split vs whole utterance of the same fp32 arithmetic:" % (N, used))
+    for w in warms:
+        print("  warm-up %d periods: worst single sample %.2e of the maximum (voice %s), worst RMS %.2e" % (w, worst[w][0], worst[w][1], rms_w[w]))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--random":
+        return random_study(int(sys.argv[2]))
     seg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     print("segments of %d control periods; columns: warm-up in control periods -> nRMS (worst single sample / max)" % seg)
     for name, pd, fr in voices():
