@@ -437,12 +437,23 @@ static uint32_t split_warm_samples(const trm::Const &c)
 
 // Predicted launch time in ms per second of speech at Monet's rates (19 750 tube samples), from the measured figures of the
 // kernel forms on 256 CUs (profiles/sweep_forms_r04.txt, split_probe_r04.txt), by workgroups per CU.
+// The one-voice-per-lane kernel: a CU holds two workgroups; one per CU runs at 6.7, two at 7.5, and more go in ROUNDS of two
+// per CU at 7.75 each -- a round is not cheaper for being partly filled (its workgroups last as long), except that a last
+// round of at most one workgroup per CU saves ~0.8 (measured at 2.5 .. 10 workgroups per CU).
+static double wide_cost(const trm_batch *b, uint64_t workgroups)
+{
+    const double cus = b->cus > 0 ? b->cus : 256, x = (double)workgroups / cus;
+    if (x <= 1.0) return 6.7;
+    if (x <= 2.0) return 7.5;
+    const double rounds = ceil(x / 2.0), last = x - 2.0 * (rounds - 1.0);
+    return 7.75 * rounds - (last <= 1.0 ? 0.8 : 0.0);
+}
 static double unsplit_cost(const trm_batch *b, size_t nvoices, int which)
 {
     const double cus = b->cus > 0 ? b->cus : 256, vpc = (double)nvoices / cus;
     if (which == TRM_KERNEL_OCT) return vpc <= 4 ? 2.06 : vpc <= 8 ? 2.24 : 2.37 * (vpc <= 16 ? 1.0 : vpc / 16.0);
     if (which == TRM_KERNEL_QUAD) return vpc <= 16 ? 3.1 : vpc <= 32 ? 4.1 : 4.1 * vpc / 32.0;
-    return vpc <= 64 ? 6.5 : vpc <= 128 ? 7.8 : 7.8 * vpc / 128.0;
+    return wide_cost(b, (nvoices + 63) / 64);
 }
 
 // segments of an utterance of P control periods cut every `periods`: the first one is periods + warm long (it has no warm-up
@@ -470,37 +481,24 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
     uint32_t periods = 0;
     if (setting > 0) periods = (uint32_t)setting;
     else {
-        // AUTO.  A time-split launch pays when its workgroups -- one per segment and block of 64 voices -- find room on the
-        // chip at once: the one-voice-per-lane kernel runs one workgroup per CU at 6.7 and two at 7.5 ms per second of
-        // speech, and a launch that needs a second round of workgroups loses what the split gained (measured:
-        // profiles/split_probe_r04.txt).  So: the two segment counts that fill one resp. two workgroups per CU, the
-        // shorter predicted launch of the two, taken when it beats whole utterances by a tenth.
-        const double cus = b->cus > 0 ? b->cus : 256;
+        // AUTO.  A time-split launch pays when its workgroups -- one per segment and block of 64 voices, every one of them
+        // periods + warm control periods long -- fill the chip's rounds better than whole utterances do (wide_cost): every
+        // segment count is priced, the shortest predicted launch taken when it beats whole utterances by a tenth.
         const double whole = unsplit_cost(b, nvoices, which) * P * CP / 19750.0;
         double best = whole * 0.9;
         // (segments of at least half a warm-up: a launch never does more than three times the arithmetic of whole
         // utterances -- shorter ones still shorten a nearly empty chip's launch a little, at ten times the work)
         uint32_t minPeriods = (255u + CP) / CP > 4u ? (255u + CP) / CP : 4u;
         minPeriods = minPeriods > (warm + 1) / 2 ? minPeriods : (warm + 1) / 2;
-        for (int perCu = 1; perCu <= 2; perCu++) {
-            // workgroups of a launch cut every sp periods (the first segment sp + warm: split_segments): per segment the
-            // blocks of 64 voices that reach it
-            auto workgroups = [&](uint32_t sp) -> uint64_t {
-                const uint64_t nseg = split_segments(P, sp, warm);
-                if (totalPeriods == 0) return nseg * ((nvoices + 63) / 64);
-                return (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (nseg + 1) / 2;      // (+ the segments' partly filled last blocks)
-            };
-            // the shortest segment whose launch still fits perCu workgroups per CU
-            uint32_t lo = minPeriods, hi = P;
-            if (workgroups(hi) > (uint64_t)(perCu * cus)) continue;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) / 2;
-                if (workgroups(mid) <= (uint64_t)(perCu * cus)) hi = mid; else lo = mid + 1;
-            }
-            const uint32_t sp = lo;
-            if (split_segments(P, sp, warm) < 2) continue;
-            // (measured, profiles/split_probe_r04.txt: one workgroup per CU 6.4-6.7 ms per second of speech, two 7.2-7.6)
-            const double t = 0.03 + (perCu == 1 ? 6.7 : 7.5) * (double)(sp + warm) * CP / 19750.0;
+        for (uint32_t nseg = 2; nseg <= 4096 && P > warm; nseg++) {
+            const uint32_t sp = (P - warm + nseg - 1) / nseg;          // the shortest segments that make `nseg` of them
+            if (sp < minPeriods) break;
+            const uint64_t segs = split_segments(P, sp, warm);
+            if (segs < 2) continue;
+            // workgroups: per segment the blocks of 64 voices that reach it
+            const uint64_t wgs = totalPeriods == 0 ? segs * ((nvoices + 63) / 64)
+                                                   : (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (segs + 1) / 2;      // (+ partly filled last blocks)
+            const double t = 0.03 + wide_cost(b, wgs) * (double)(sp + warm) * CP / 19750.0;
             if (t < best) { best = t; periods = sp; }
         }
     }
