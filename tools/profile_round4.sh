@@ -6,8 +6,10 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 R=gpurun_out/prof_r04
 mkdir -p $R
-bash tools/profile_workload.sh r04_config1 --no-stream > $R/prof_config1.log 2>&1
-bash tools/profile_workload.sh r04_config2 --config 2 > $R/prof_config2.log 2>&1
+# (a time-split launch = two trm_tube_kernel dispatches: the segment instance and the gated whole-utterance one that returns at once)
+TRM_SUMMARY_DISPATCHES=2 bash tools/profile_workload.sh r04_config1 --no-stream > $R/prof_config1.log 2>&1
+TRM_SUMMARY_DISPATCHES=2 bash tools/profile_workload.sh r04_config2 --config 2 > $R/prof_config2.log 2>&1
+bash tools/profile_workload.sh r04_config1_whole --no-stream --split off > $R/prof_config1_whole.log 2>&1
 TRM_SUMMARY_DISPATCHES=2 bash tools/profile_workload.sh r04_config3 --config 3 --no-end-to-end > $R/prof_config3.log 2>&1
 TRM_SUMMARY_DISPATCHES=2 bash tools/profile_workload.sh r04_config4 --config 4 > $R/prof_config4.log 2>&1
 bash tools/profile_workload.sh r04_config4_whole --config 4 --split off > $R/prof_config4_whole.log 2>&1
@@ -19,5 +21,7 @@ for v in 64 256 512 1024 1536 2048 3072 4096 5120 6144 7168 8192 9216 10240 1126
   done
 done > $R/sweep_auto.txt
 cat $R/sweep_auto.txt
+python tools/single_voice_latency.py > $R/single_voice.txt 2>&1; tail -6 $R/single_voice.txt
+python tools/bench_rates.py > $R/rates.txt 2>&1; head -5 $R/rates.txt
 python tools/fuzz_parity.py 0 120 > $R/fuzz_parity.txt 2>&1; tail -4 $R/fuzz_parity.txt
 python tools/fuzz_parity.py 0 60 300 broad > $R/fuzz_parity_broad.txt 2>&1; tail -4 $R/fuzz_parity_broad.txt
