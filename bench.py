@@ -185,7 +185,7 @@ CONFIGS = {1: (4096, "static"), 2: (4096, "timevarying"), 3: (1024, "ragged"), 4
 # microbenchmark under the counters (profiles/valu_pmc_calibration_r04.txt): SQ_ACTIVE_INST_VALU charges ONE quad-cycle per
 # instruction of any class (two per transcendental), i.e. it counts instructions, not busy SIMD cycles -- round 3's
 # "4 x SQ_ACTIVE_INST_VALU = the launch's SIMD cycles: the VALUs never idle" is withdrawn and these class prices are back.
-ISSUE_CYCLES = {"oct": 3.32, "quad": 3.45, "wide": 3.10, "wide/split": 3.22}
+ISSUE_CYCLES = {"oct": 3.32, "quad": 3.45, "wide": 3.10, "wide/split": 3.22, "quad/split": 3.37}
 
 
 def lookup_traffic(voices, nframes, kind, form, avg_launch_s):
@@ -460,7 +460,8 @@ def main():
     form = b.last_kernel + ("/split" if split[0] else "")
     traffic, valu, traffic_note = lookup_traffic(voices, nframes, workload, form, avg_launch_s)
     kernel_name = {"wide": "trm_tube_kernel<0>", "quad": "trm_tube_kernel_q", "oct": "trm_tube_kernel_o",
-                   "wide/split": "trm_tube_kernel<2> (+ trm_phase_period_kernel, trm_phase_segment_kernel)"}[form]
+                   "wide/split": "trm_tube_kernel<2> (+ trm_phase_period_kernel, trm_phase_segment_kernel)",
+                   "quad/split": "trm_tube_kernel_q<true, 2, true> (+ trm_phase_period_kernel, trm_phase_segment_kernel)"}[form]
     out = {
         "metric": "audio samples/s (whole node) + concurrent real-time tube voices",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -108,6 +108,7 @@ struct trm_batch {
     // time-split launches (trm_batch_set_time_split)
     int splitSetting = TRM_TIME_SPLIT_AUTO;      // AUTO, OFF, or a segment length in control periods
     uint32_t lastSplitPeriods = 0, lastSplitWarm = 0;      // what the last launch did (0: whole utterances)
+    int lastSplitForm = TRM_KERNEL_WIDE;
     DevBuf<double> dSegPhase, dPeriodAdv;
     uint32_t *dGate = nullptr;
     uint64_t hintTotalPeriods = 0;       // set by the host-buffer entries (they see every voice's length) for the launch that follows
@@ -412,6 +413,7 @@ namespace {
 struct SplitPlan {
     uint32_t periods = 0;         // control periods per segment; 0 = whole utterances
     uint32_t warm = 0;            // warm-up control periods
+    int form = TRM_KERNEL_WIDE;   // the segment instance that runs it: one voice per lane (64 voices per workgroup) or four lanes per voice (16)
     float bwFloor = 0.0f;         // frication bandwidths below this need a longer warm-up: the launch falls back (device-side)
 };
 // ln(1e-5): what is left of the state the warm-up starts without.  Measured (tools/timesplit_study.py, 180 random and
@@ -466,7 +468,7 @@ static uint32_t split_segments(uint32_t P, uint32_t periods, uint32_t warm)
 
 // `which` = the kernel form the launch would take unsplit.  `totalPeriods` = the control periods of all voices together where
 // the caller knows them (the host-buffer entries; 0: every voice is taken to be as long as the longest).
-static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, uint64_t totalPeriods, SplitPlan &pl)
+static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, int byName, uint64_t totalPeriods, SplitPlan &pl)
 {
     pl = SplitPlan();
     const int setting = b->splitSetting;
@@ -479,8 +481,15 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
     }
     const uint32_t warm = (ws + CP - 1) / CP;
     uint32_t periods = 0;
-    if (setting > 0) periods = (uint32_t)setting;
-    else {
+    // the four-lane segment instance: up-sampling batches whose converter makes at most four outputs per tube sample
+    const bool quadOk = b->c.upsample && !quad_ratio_too_high(b->c) && which != TRM_KERNEL_WIDE;
+    if (setting > 0) {
+        periods = (uint32_t)setting;
+        // a split asked for by name: in the form asked for by name (four lanes, or one voice per lane), else by size
+        const uint64_t wgsQ = (uint64_t)split_segments(P, periods, warm) * ((nvoices + 15) / 16);
+        pl.form = (quadOk && (byName == TRM_KERNEL_QUAD || (byName == TRM_KERNEL_AUTO && wgsQ <= (uint64_t)(b->cus > 0 ? b->cus : 256)))) ? TRM_KERNEL_QUAD
+                                                                                                                                       : TRM_KERNEL_WIDE;
+    } else {
         // AUTO.  A time-split launch pays when its workgroups -- one per segment and block of 64 voices, every one of them
         // periods + warm control periods long -- fill the chip's rounds better than whole utterances do (wide_cost): every
         // segment count is priced, the shortest predicted launch taken when it beats whole utterances by a tenth.
@@ -499,7 +508,14 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
             const uint64_t wgs = totalPeriods == 0 ? segs * ((nvoices + 63) / 64)
                                                    : (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (segs + 1) / 2;      // (+ partly filled last blocks)
             const double t = 0.03 + wide_cost(b, wgs) * (double)(sp + warm) * CP / 19750.0;
-            if (t < best) { best = t; periods = sp; }
+            if (t < best) { best = t; periods = sp; pl.form = TRM_KERNEL_WIDE; }
+            // ... or in the four-lane form (16 voices x one segment per workgroup, one workgroup per CU at 3.1 ms per second of
+            // speech): a handful of voices, a single utterance
+            const uint64_t wgsQ = totalPeriods == 0 ? segs * ((nvoices + 15) / 16) : (totalPeriods + 16ull * sp - 1) / (16ull * sp) + (segs + 1) / 2;
+            if (quadOk && wgsQ <= (uint64_t)(b->cus > 0 ? b->cus : 256)) {
+                const double tq = 0.03 + 3.1 * (double)(sp + warm) * CP / 19750.0;
+                if (tq < best) { best = tq; periods = sp; pl.form = TRM_KERNEL_QUAD; }
+            }
         }
     }
     if (periods == 0 || split_segments(P, periods, warm) < 2) return TRM_OK;      // one segment is the whole utterance
@@ -629,15 +645,17 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     // the caller asked for by name is run as asked (whole utterances) unless the split was asked for by name too.
     SplitPlan pl;
     const bool formByName = b->kernel != TRM_KERNEL_AUTO || b->envKernel != TRM_KERNEL_AUTO;
-    if (!(formByName && b->splitSetting <= 0) && (rc = plan_time_split(b, nvoices, max_nframes, which, b->hintTotalPeriods, pl))) return rc;
+    const int byName = b->kernel != TRM_KERNEL_AUTO ? b->kernel : b->envKernel;
+    if (!(formByName && b->splitSetting <= 0) && (rc = plan_time_split(b, nvoices, max_nframes, which, byName, b->hintTotalPeriods, pl))) return rc;
     b->hintTotalPeriods = 0;                          // (a hint holds for one launch)
     b->lastSplitPeriods = pl.periods;
     b->lastSplitWarm = pl.periods ? pl.warm : 0;
     if (pl.periods) {
         const uint32_t nseg = split_segments(max_nframes - 1, pl.periods, pl.warm);
-        const uint32_t wgPerSeg = (uint32_t)((nvoices + 63) / 64);
+        const uint32_t perWg = pl.form == TRM_KERNEL_QUAD ? 16u : 64u;
+        const uint32_t wgPerSeg = (uint32_t)((nvoices + perWg - 1) / perWg);
         if ((uint64_t)nseg * wgPerSeg > 0x7FFFFFFFull / 64) return fail(TRM_ERANGE, "time split: too many segments");
-        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * 64)) || (rc = b->dPeriodAdv.reserve(nvoices * (size_t)max_nframes))) return rc;
+        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * perWg)) || (rc = b->dPeriodAdv.reserve(nvoices * (size_t)max_nframes))) return rc;
         HIP_TRY(hipMemsetAsync(b->dGate, 0, sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_max_sample, 0, nvoices * sizeof(float), stream));
         trm::PhaseArgs ph;
@@ -645,19 +663,22 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         ph.period_adv = b->dPeriodAdv.p; ph.seg_phase = b->dSegPhase.p; ph.gate = b->dGate; ph.bw_floor = pl.bwFloor;
         ph.nvoices = (uint32_t)nvoices; ph.max_nframes = max_nframes; ph.nseg = nseg;
         ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg; ph.seg_first = pl.periods + pl.warm;
+        ph.voices_per_wg = perWg;
         HIP_TRY(trm::launch_phase(b->c, ph, stream));
         trm::TubeArgs sa = a;
         sa.seg_periods = pl.periods; sa.seg_warm = pl.warm; sa.seg_wg_per_seg = wgPerSeg; sa.seg_grid = nseg * wgPerSeg;
         sa.seg_first = pl.periods + pl.warm;
         sa.seg_phase = b->dSegPhase.p;
         sa.gate = b->dGate; sa.gate_want = 0;
-        HIP_TRY(trm::launch_tube(b->c, sa, stream));
+        if (pl.form == TRM_KERNEL_QUAD) HIP_TRY(trm::launch_tube_quad(b->c, sa, stream, b->cus));
+        else HIP_TRY(trm::launch_tube(b->c, sa, stream));
+        b->lastSplitForm = pl.form;
         // ... and, should the pre-pass have found a track the warm-up does not cover, whole utterances (the launch below
         // returns at once otherwise)
         a.gate = b->dGate; a.gate_want = 1;
         which = TRM_KERNEL_WIDE;
     }
-    b->lastKernel = which;
+    b->lastKernel = pl.periods ? b->lastSplitForm : which;
     if (which == TRM_KERNEL_OCT)
         HIP_TRY(trm::launch_tube_oct(b->c, a, stream));
     else if (which == TRM_KERNEL_QUAD)

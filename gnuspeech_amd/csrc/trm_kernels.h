@@ -50,6 +50,7 @@ struct TubeArgs {
     // trm_capi.cc plan_time_split), and emits the converter outputs whose read position lies in the segment proper.  What a
     // segment cannot reconstruct from the frames is the oscillator position: seg_phase[q * 64 * seg_wg_per_seg + v] is the
     // (wrapped) advance of voice v's oscillator between the warm-up starts of segments q - 1 and q (trm_phase_segment_kernel);
+    // (seg_phase's row pitch is seg_wg_per_seg x the voices of a workgroup: 64 here, 16 in trm_tube_kernel_q's segment instance)
     // the kernel sums q = 1 .. its own segment (exact sums: osc_increment).  max_sample is folded with an atomic max
     // (zeroed by the launcher), number_samples written by segment 0.
     uint32_t seg_periods = 0, seg_warm = 0, seg_wg_per_seg = 0;
@@ -76,6 +77,7 @@ struct PhaseArgs {
     uint32_t *gate;
     float bw_floor;
     uint32_t nvoices, max_nframes, nseg, seg_periods, seg_warm, seg_wg_per_seg, seg_first;
+    uint32_t voices_per_wg;       // of the tube kernel that follows: 64 (trm_tube_kernel) or 16 (trm_tube_kernel_q)
 };
 hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream);
 

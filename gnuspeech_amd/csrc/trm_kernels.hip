@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void trm_phase_period_kernel(const Const C, co
 
 __global__ __launch_bounds__(256) void trm_phase_segment_kernel(const Const C, const PhaseArgs P)
 {
-    const uint32_t lanes = P.seg_wg_per_seg * kWave;
+    const uint32_t lanes = P.seg_wg_per_seg * P.voices_per_wg;      // (the tube kernel's index pitch: 64 voices per workgroup, or 16)
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = idx / lanes, v = idx - q * lanes;
     if (q + 1 >= P.nseg || v >= P.nvoices) return;
@@ -979,7 +979,7 @@ hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream)
     if (a.nvoices == 0 || a.nseg == 0) return hipSuccess;
     const uint64_t periods = (uint64_t)a.nvoices * a.max_nframes;
     hipLaunchKernelGGL(trm_phase_period_kernel, dim3((unsigned)((periods + 255) / 256)), dim3(256), 0, stream, c, a);
-    const uint64_t threads = (uint64_t)(a.nseg - 1) * a.seg_wg_per_seg * kWave;
+    const uint64_t threads = (uint64_t)(a.nseg - 1) * a.seg_wg_per_seg * a.voices_per_wg;
     if (threads > 0) hipLaunchKernelGGL(trm_phase_segment_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }

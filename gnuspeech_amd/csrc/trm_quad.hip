@@ -91,9 +91,15 @@ struct QuadLds {
 };
 
 // kSub: blocks per pipeline step (see the top of the file).
-template <bool kStream, int kSub>
+// kSeg (with kStream): a TIME-SPLIT launch (trm_kernels.h, TubeArgs::seg_*; round 4): the streaming instance's time bases,
+// per workgroup -- workgroup w runs segment w / seg_wg_per_seg of 16 voices from rest, a warm-up ahead --, no state in or
+// out.  What the one-voice-per-lane kernel's segment instance is for batches that fill the chip, this one is for a handful of
+// voices: a single utterance becomes sixteen lanes' worth of segments on one CU.
+template <bool kStream, int kSub, bool kSeg = false>
 __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Const C, const TubeArgs A)
 {
+    static_assert(!kSeg || kStream, "the segment instance is built on the streaming instance");
+    if (kSeg && A.gate && ((*A.gate != 0u) ? 1u : 0u) != A.gate_want) return;      // (two launches, the device runs one: TubeArgs::gate)
     constexpr int kStepN = kQB * kSub;       // tube samples per step
     typedef QuadLds<kSub> L;
     constexpr int kXBufs = L::kXBufs, kKBufs = L::kKBufs, kABufs = L::kABufs;
@@ -130,28 +136,56 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     // lane -> (voice, slot/part): a row of 16 lanes = 4 banks (slot/part) x 4 voices
     const int part = (lane >> 2) & 3;
     const int vq = (lane >> 4) * 4 + (lane & 3);        // voice within the workgroup
-    const uint32_t vRaw = blockIdx.x * kQV + vq;
+    // time-split: workgroup -> (segment, block of 16 voices)
+    const uint32_t seg = kSeg ? blockIdx.x / A.seg_wg_per_seg : 0u;
+    const uint32_t vblock = kSeg ? blockIdx.x - seg * A.seg_wg_per_seg : blockIdx.x;
+    const uint32_t vRaw = vblock * kQV + vq;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
-
-    const uint32_t nfr = min(A.nframes[v], A.max_nframes);
-    const uint32_t nfrMax = wave_max_u32(nfr);
     const uint32_t CP = (uint32_t)C.controlPeriod;
     const uint32_t inc = C.timeRegisterIncrement;
+    auto outputs_before = [&](uint64_t end) { return end == 0 ? 0u : (uint32_t)(((end << 16) - 1) / inc + 1); };
+    auto seg_begin = [&](uint32_t sgm) { return sgm == 0 ? 0u : A.seg_first + (sgm - 1) * A.seg_periods; };
+
+    const uint32_t nfrAll = min(A.nframes[v], A.max_nframes);
+    // the frames this launch runs for this lane: the utterance's (chunk's), or those of the workgroup's segment with its warm-up
+    uint32_t nfr = nfrAll, segFrame0 = 0, segOutEnd = 0;
+    bool segLast = true;
+    if (kSeg) {
+        const uint32_t nper = nfrAll > 0 ? nfrAll - 1 : 0;
+        const uint32_t pLo = seg_begin(seg), pEnd = seg_begin(seg + 1);
+        segFrame0 = pLo > A.seg_warm ? pLo - A.seg_warm : 0u;
+        if (seg > 0 && pLo >= nper) nfr = 0;
+        else if (nfrAll > 0) {
+            const uint32_t pHi = pEnd < nper ? pEnd : nper;
+            nfr = pHi - segFrame0 + 1;
+            segLast = pHi == nper;
+            segOutEnd = outputs_before((uint64_t)pHi * CP);
+        }
+    }
+    const uint32_t nfrMax = wave_max_u32(nfr);
     const uint32_t ntubeMax = nfrMax > 0 ? (nfrMax - 1) * CP : 0;
     // streaming: this launch is one chunk of a longer utterance (trm_kernels.h); one-shot = first and last at once
     constexpr bool streaming = kStream;
-    const bool sFirst = !streaming || (A.stream_flags & 1u), sLast = !streaming || (A.stream_flags & 2u);
+    constexpr bool saving = kStream && !kSeg;        // state out at the chunk's last sample (a segment starts from rest and leaves nothing)
+    const bool sFirst = !streaming || kSeg || (A.stream_flags & 1u), sLast = !streaming || kSeg || (A.stream_flags & 2u);
     // TRAcT's loop (Applications/TRAcT/tube.c:1121-1136) reads the parameter set every sample and never interpolates: a
     // control period then runs on the frame that ENDS it, held (trm_stream_set_mode)
-    const bool sHold = streaming && (A.stream_flags & 4u);
-    const uint32_t nBase = streaming ? A.stream_n_base : 0u, kBase = streaming ? A.stream_k_base : 0u;
-    float *const st = streaming ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
+    const bool sHold = streaming && !kSeg && (A.stream_flags & 4u);
+    const uint32_t nBase = kSeg ? segFrame0 * CP : streaming ? A.stream_n_base : 0u;
+    const uint32_t kBase = kSeg ? outputs_before((uint64_t)seg_begin(seg) * CP) : streaming ? A.stream_k_base : 0u;
+    float *const st = saving ? A.stream_state + (size_t)v * kStreamFloats : nullptr;
+    // outputs of this launch for this lane's voice (segments: its own stretch; the voice's last segment runs to the utterance's end)
+    uint32_t noutSeg = 0, noutAll = 0;
+    if (kSeg) {
+        if (nfrAll > 0) noutAll = (uint32_t)((((uint64_t)(nfrAll - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);
+        noutSeg = (nfr > 0 && laneValid) ? (segLast ? noutAll : segOutEnd) - kBase : 0u;
+    }
     // tube samples the tube stage produces: the utterance (chunk), then the converter's 2*pad zero flush (TRMRingBuffer.m:85-93)
     const uint32_t nTotal = nfrMax > 0 ? ntubeMax + (sLast ? 2u * (uint32_t)C.padSize : 0u) : 0;
     // the tube stage steps the blocks of step i-4 at step i; the convert wave finishes what is queued after the last barrier
     const uint32_t nSteps = nTotal > 0 ? (nTotal + kStepN - 1) / kStepN + 5 : 0;
-    const float *frames = A.frames + (nfr > 0 ? A.frame_offset[v] * 16 : 0);
+    const float *frames = A.frames + (nfr > 0 ? (A.frame_offset[v] + segFrame0) * 16 : 0);
     const uint32_t ntubeLane = nfr > 0 ? (nfr - 1) * CP : 0;
     const uint32_t ntubeMin = wave_min_u32(ntubeLane);      // every voice of the group is still sounding below this
     auto frame_index = [&](uint32_t i) { return nfr > 0 ? (i < nfr ? i : nfr - 1) : 0u; };
@@ -167,7 +201,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     const float *stageSrc = nullptr;
     uint32_t stageNfr = 0;
     if (kLdsFrames && role == 2) {
-        const uint32_t sv = min(blockIdx.x * kQV + ((uint32_t)lane >> 2), A.nvoices - 1);
+        const uint32_t sv = min(vblock * kQV + ((uint32_t)lane >> 2), A.nvoices - 1);
         stageNfr = min(A.nframes[sv], A.max_nframes);
         stageSrc = A.frames + (stageNfr > 0 ? A.frame_offset[sv] * 16 : 0) + (lane & 3) * 4;
     }
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         __syncthreads();
         for (int i = threadIdx.x; i < kQV * 32; i += kWave * kQRoles) {
             const int q = i >> 5, t = i & 31;
-            const uint32_t vv = blockIdx.x * kQV + q < A.nvoices ? blockIdx.x * kQV + q : A.nvoices - 1;
+            const uint32_t vv = vblock * kQV + q < A.nvoices ? vblock * kQV + q : A.nvoices - 1;
             const float *h = A.stream_state + (size_t)vv * kStreamFloats;
             sO[q * kOStride + 32 + t] = make_float2(h[8 + 2 * t], h[9 + 2 * t]);            // slot (-32 + t) & 63
             const uint32_t slot = (uint32_t)(t - 32 + kQLead) & (kYRing - 1);
@@ -232,7 +266,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         Z.by1 = q_take<0, kPart0>(Z.by1, Z.ny1);
         Z.by2 = q_take<0, kPart0 | kPart1>(Z.by2, Z.ny2);
         Z.prevSig = sig;
-        if (streaming) {
+        if (saving) {
             const uint32_t n = blk * kQB + (uint32_t)part;
             if (n + 2u == ntubeLane) { st[4] = f; st[6] = sig; }
             if (n + 1u == ntubeLane) { st[5] = f; st[7] = sig; }
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             if (t == 3) Z.thNext = q_take<1, kPart0>(Z.thNext, ty);
         }
         Z.thY = q_take<0, kPart0>(Z.thY, Z.thNext);
-        if (streaming && m + 1u == ntubeLane) st[2] = ty;
+        if (saving && m + 1u == ntubeLane) st[2] = ty;
         return ty;
     };
 
@@ -270,6 +304,13 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         OscSlotTrack T;
         double P = 0.0;                                 // oscillator position at the start of the block
         if (streaming && !sFirst) P = *reinterpret_cast<const double *>(st);
+        if (kSeg) {
+            // the oscillator's position at the warm-up start: the advances between the warm-up starts of the segments so far
+            // (trm_phase_segment_kernel), summed and wrapped in order -- exact
+            const double *ph = A.seg_phase + vRaw;
+            const size_t pitch = (size_t)A.seg_wg_per_seg * kQV;
+            for (uint32_t q = 1; q <= seg; q++) P = osc_wrap(P + ph[q * pitch]);
+        }
         float prev[4], cur[4], nxt[4];                  // (streaming instance: the frames carried in registers)
         uint32_t per = 0, j = (uint32_t)part;           // control period / position in it of this lane's sample
         if (nSteps > 0) {
@@ -331,7 +372,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 pre += q_take<2, kPart2 | kPart3>(0.0, pre);
                 const double end = P + pre;
                 const double pos2 = osc_wrap(end), pos1 = osc_wrap(end - oinc);
-                if (streaming && oblk * kQB + (uint32_t)part + 1u == ntubeLane) *reinterpret_cast<double *>(st) = pos2;   // the chunk's last sample
+                if (saving && oblk * kQB + (uint32_t)part + 1u == ntubeLane) *reinterpret_cast<double *>(st) = pos2;   // the chunk's last sample
                 double tot = pre;                                // slot 3's prefix = the block's advance
                 tot = q_take<1, kPart0>(tot, pre);
                 tot = q_take<2, kPart1>(tot, pre);
@@ -353,7 +394,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             STAMP_END
         }
         STAMP_STORE(role)
-        if (streaming && laneValid) {
+        if (saving && laneValid) {
             // the chunk's last 32 oscillator reads (positions N-32 .. N-1; older than the chunk: still in the ring)
             for (int t = part; t < 32; t += 4) {
                 const float2 x = ring[(ntubeLane - 32u + (uint32_t)t) & (kORing - 1)];
@@ -366,8 +407,9 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         __builtin_amdgcn_s_setprio(TRM_QPRIO_MIX);
 #endif
         // ------------------------------------------------------------ mix: block i-1 at step i, lane = (voice, slot)
+        const float *const lpNoise = A.lp_noise + (kSeg ? nBase : 0u);      // (a stream's pointer arrives advanced)
         auto fill_noise_half = [&](uint32_t nFirst, int half) {
-            dma4(A.lp_noise + nFirst + lane, &sNoise[half * kNoiseHalf]);
+            dma4(lpNoise + nFirst + lane, &sNoise[half * kNoiseHalf]);
         };
         // window taps of this lane's parity (m & 1 == part & 1: blocks start on multiples of 4), as (a, b) pairs
         const int o = part & 1;
@@ -392,7 +434,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         uint32_t rowBlk = 0;
         bool rowsInFlight = false;
         float4 rq[4];
-        const uint32_t cvtOutputs = streaming ? A.stream_k_end - kBase
+        const uint32_t cvtOutputs = kSeg ? wave_max_u32(noutSeg) : streaming ? A.stream_k_end - kBase
                                               : wave_max_u32(laneValid && nfr > 0 ? (uint32_t)((((uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc) : 0u);
         const uint32_t cvtBlocks = C.upsample ? (cvtOutputs + kCvtCols - 1) / kCvtCols : 0;
         STAMP_DECL
@@ -554,7 +596,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
         __builtin_amdgcn_s_setprio(TRM_QPRIO_TUBE);
         QuadState<float> S;
         quad_reset(S);
-        float *const stTube = streaming ? st + 104 + 20 * part : nullptr;
+        float *const stTube = saving ? st + 104 + 20 * part : nullptr;
         if (streaming && !sFirst) {
             S.TA = v2f_t{stTube[0], stTube[1]}; S.TB = v2f_t{stTube[2], stTube[3]};
             S.BA = v2f_t{stTube[4], stTube[5]}; S.BB = v2f_t{stTube[6], stTube[7]};
@@ -605,7 +647,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 float y[kQB];
                 // (samples past nTotal in the last block step on stale inputs; their output is forced to 0)
                 // (streaming: the state after the chunk's last sample is what the next chunk starts from)
-                const bool saveHere = streaming && n0 < ntubeLane && n0 + kQB >= ntubeLane;      // uniform
+                const bool saveHere = saving && n0 < ntubeLane && n0 + kQB >= ntubeLane;      // uniform
                 y[0] = step_one(head);
                 if (saveHere && n0 + 1 == ntubeLane) save_state();
                 y[1] = step_one(i1);
@@ -648,14 +690,16 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
 #endif
         // ------------------------------------------------------------ convert (lane = output time), 16 voices
         uint32_t noutLane = 0;
-        if (streaming) {
+        if (kSeg) {
+            noutLane = noutSeg;
+        } else if (streaming) {
             noutLane = A.stream_k_end - kBase;
         } else if (nfr > 0) {
             uint64_t total = (uint64_t)ntubeLane + 2ull * (uint32_t)C.padSize;
             noutLane = (uint32_t)((total * 65536ull + inc - 1) / inc);
         }
         if (!laneValid) noutLane = 0;
-        const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v]);
+        const uintptr_t myOut = reinterpret_cast<uintptr_t>(A.out + A.out_offset[v] + (kSeg ? kBase : 0u));
         const uint32_t noutMax = wave_max_u32(noutLane);
         const uint32_t nBlocks = C.upsample ? (noutMax + kCvtCols - 1) / kCvtCols : 0;
         const int col = lane & (kCvtCols - 1);
@@ -771,7 +815,7 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
                 do_pair();
             }
         }
-        if (streaming && laneValid && part < 2) {
+        if (saving && laneValid && part < 2) {
             // the chunk's last 32 tube samples (positions N-32 .. N-1) for the next chunk's converter
             for (int t = part; t < 32; t += 2)
                 st[72 + t] = sY[vq * kYStride + ((ntubeLane - 32u + (uint32_t)t + kQLead) & (kYRing - 1))];
@@ -785,14 +829,20 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
             if (lane == 2 * r) myMax = lowHalf;
             if (lane == 2 * r + 1) myMax = highHalf;
         }
-        const uint32_t ov = blockIdx.x * kQV + (uint32_t)lane;
+        const uint32_t ov = vblock * kQV + (uint32_t)lane;
         if (lane < kQV && ov < A.nvoices && C.upsample) {
             const uint32_t nf = min(A.nframes[ov], A.max_nframes);
             uint32_t nov = 0;
-            if (streaming) nov = A.stream_k_end - kBase;
+            if (streaming && !kSeg) nov = A.stream_k_end - kBase;
             else if (nf > 0) nov = (uint32_t)((((uint64_t)(nf - 1) * CP + 2ull * (uint32_t)C.padSize) * 65536ull + inc - 1) / inc);
-            A.number_samples[ov] = nov;
-            A.max_sample[ov] = myMax;
+            if (kSeg) {
+                // (max_sample was zeroed by the launcher; non-negative floats order like their bit patterns)
+                if (seg == 0) A.number_samples[ov] = nov;
+                if (myMax > 0.0f) atomicMax(reinterpret_cast<unsigned int *>(&A.max_sample[ov]), __float_as_uint(myMax));
+            } else {
+                A.number_samples[ov] = nov;
+                A.max_sample[ov] = myMax;
+            }
         }
         return;
     }
@@ -800,13 +850,13 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
 
 // `cus`: the device's compute units.  A batch of more workgroups than that runs the instance that fits two of them on
 // a CU (kSub = 1); up to one workgroup per CU the instance with two independent blocks per step (kSub = 2).
-template <bool kStream, int kSub>
+template <bool kStream, int kSub, bool kSeg = false>
 static hipError_t launch_instance(const Const &c, const TubeArgs &a, hipStream_t stream, uint32_t grid)
 {
     static DynamicLdsAllowance lds;
-    hipError_t e = lds.ensure(reinterpret_cast<const void *>(trm_tube_kernel_q<kStream, kSub>), (int)QuadLds<kSub>::kBytes);
+    hipError_t e = lds.ensure(reinterpret_cast<const void *>(trm_tube_kernel_q<kStream, kSub, kSeg>), (int)QuadLds<kSub>::kBytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((trm_tube_kernel_q<kStream, kSub>), dim3(grid), dim3(kWave * kQRoles), QuadLds<kSub>::kBytes, stream, c, a);
+    hipLaunchKernelGGL((trm_tube_kernel_q<kStream, kSub, kSeg>), dim3(grid), dim3(kWave * kQRoles), QuadLds<kSub>::kBytes, stream, c, a);
     return hipGetLastError();
 }
 
@@ -814,6 +864,7 @@ hipError_t launch_tube_quad(const Const &c, const TubeArgs &a, hipStream_t strea
 {
     if (a.nvoices == 0) return hipSuccess;
     uint32_t grid = (a.nvoices + kQV - 1) / kQV;
+    if (a.seg_periods) return launch_instance<true, 2, true>(c, a, stream, a.seg_grid);      // time split: 16 voices x one segment per workgroup
     if (a.stream_state) return launch_instance<true, 2>(c, a, stream, grid);
     // one-shot instances stage the control frames in a ring of four: frame p+3 replaces frame p-1 one step into period p,
     // and the coefficient waves' last lanes read frame p-1 three steps into period p-1 -- a period must hold three steps

@@ -232,7 +232,7 @@ def test_no_kernel_spills_or_outgrows_its_register_budget(tmp_path):
             get = lambda key: int(re.search(key + r":\s+(\d+)", blk).group(1))
             kernels[name.group(1)] = (get(r"\.private_segment_fixed_size"), get(r"\.sgpr_spill_count"), get(r"\.vgpr_spill_count"), get(r"\.vgpr_count"))
     tube = [k for k in kernels if "trm_tube_kernel" in k]
-    assert len(tube) == 7, sorted(kernels)           # wide x3 (one-shot, stream, time-split), quad x3, oct
+    assert len(tube) == 8, sorted(kernels)           # wide x3 (one-shot, stream, time-split), quad x4 (+ its time-split instance), oct
     for k, (scratch, sspill, vspill, vgprs) in kernels.items():
         assert scratch == 0 and sspill == 0 and vspill == 0, (k, scratch, sspill, vspill)
     for k in tube:

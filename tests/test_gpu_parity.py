@@ -222,6 +222,7 @@ def test_eight_lane_form_runs_where_it_applies(g, monkeypatch):
     voices = [rows[:90].copy(), rows[40:200].copy(), rows[5:7].copy()]
     pd = cases.monet_default_params(44100.0)
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
+    b.set_time_split("off")                             # (whole utterances: AUTO's choice among the three layouts)
     b.synthesize(voices)
     assert b.last_kernel == "oct"                       # AUTO, small batch
     pd["controlRate"] = 1000.0
@@ -235,6 +236,7 @@ def test_eight_lane_form_runs_where_it_applies(g, monkeypatch):
     pd["length"] = 20.0                                 # control period 18: two eight-sample steps fit
     b = g.TRMBatch(g.TRMInputParameters.from_dict(pd))
     assert 16 <= b.derived["controlPeriod"] < 24
+    b.set_time_split("off")
     b.synthesize(voices)
     assert b.last_kernel == "oct"
     _batch_vs_oracle(g, pd, voices)

@@ -115,16 +115,19 @@ def _batch(g, pd, split):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", UP_CASES)
 @pytest.mark.parametrize("seg", [5, 9, 40])
-def test_split_launch_matches_reference_fixture(g, name, seg):
-    """Every up-sampling fixture, cut every `seg` control periods, against what the reference's C tube produced."""
+@pytest.mark.parametrize("form", ["wide", "quad"])
+def test_split_launch_matches_reference_fixture(g, name, seg, form):
+    """Every up-sampling fixture, cut every `seg` control periods, against what the reference's C tube produced -- in both
+    segment instances: one voice per lane (64 voices x one segment per workgroup) and four lanes per voice (16)."""
     gold = golden_io.load(name)
     b = _batch(g, gold["params_dict"], seg)
+    b.set_kernel(form)
     pcm, ns, mx = b.synthesize([gold["frames"], gold["frames"][:seg + 40].copy(), gold["frames"][:2].copy()])
     nper = len(gold["frames"]) - 1
     warm = warm_periods(gold["params_dict"], int(gold["derived"][0]))
     split = nper > seg + warm            # (the first segment is seg + warm periods long: a shorter fixture is one segment, whole)
     assert b.last_time_split == ((seg, warm) if split else (0, 0))
-    assert b.last_kernel == ("wide" if split else "oct")
+    assert b.last_kernel == form
     assert int(ns[0]) == gold["numberSamples"]
     m = gold["maximumSampleValue"]
     assert nrms(pcm[0], gold["samples_f32"].astype(np.float64), m) <= RMS_TOL
@@ -139,7 +142,31 @@ def test_split_launch_matches_reference_fixture(g, name, seg):
 
 
 @pytest.mark.gpu
-def test_split_ragged_batch_against_oracle(g):
+def test_single_utterance_runs_as_segments_of_the_four_lane_form(g):
+    """The reference's own call pattern -- ONE utterance per synthesize (TRMSynthesizer.m:118-136) -- under AUTO: a second of
+    speech becomes a dozen segments of one four-lane workgroup each; counts exact, the utterance at the tolerance; a batch of
+    64 such voices likewise; 4096 of them take the one-voice-per-lane segments."""
+    pd = cases.monet_default_params(44100.0)
+    rows = cases.load_gnuspeech_rows()
+    fr = np.concatenate([rows, rows])[:251]
+    b = _batch(g, pd, "auto")
+    op = O.InputParams.from_dict(pd)
+    o = O.synthesize(op, np.asarray(fr, dtype=np.float32).astype(np.float64))
+    for V in (1, 64):
+        pcm, ns, mx = b.synthesize([fr] * V)
+        assert b.last_kernel == "quad" and b.last_time_split[0] >= 15 and b.last_time_split[1] == 30
+        for v in (0, V - 1):
+            assert int(ns[v]) == o["numberSamples"]
+            assert nrms(pcm[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL
+            assert float(mx[v]) == float(np.abs(pcm[v]).max())
+    st = b.prepare_device(np.repeat(np.asarray(fr, dtype=np.float32)[None], 4096, axis=0))
+    b.synthesize_device(st)
+    assert b.last_kernel == "wide" and b.last_time_split[0] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["wide", "quad"])
+def test_split_ragged_batch_against_oracle(g, form):
     """BASELINE configs[3]'s shape (ragged utterances, frication and aspiration on) split every 25 control periods: exact
     counts, maxima, every voice at the tolerance; 0-, 1- and 2-frame voices ride along; 150 voices = three blocks of 64."""
     pd = cases.monet_default_params(44100.0)
@@ -147,8 +174,9 @@ def test_split_ragged_batch_against_oracle(g):
     rows = cases.load_gnuspeech_rows()
     voices += [np.zeros((0, 16)), rows[5:6].copy(), rows[100:102].copy(), cases.static_frames(MV_CLOSED, 140)]
     b = _batch(g, pd, 25)
+    b.set_kernel(form)
     pcm, ns, mx = b.synthesize(voices)
-    assert b.last_time_split == (25, 30)
+    assert b.last_time_split == (25, 30) and b.last_kernel == form
     op = O.InputParams.from_dict(pd)
     worst = 0.0
     for v, fr in enumerate(voices):
@@ -258,7 +286,7 @@ def test_auto_splits_the_sentence_batch_and_leaves_named_forms_alone(g):
     b = _batch(g, pd, "auto")
     pcm, ns, mx = b.synthesize(utt)
     sp, warm = b.last_time_split
-    assert sp > 0 and warm == 30 and b.last_kernel == "wide"
+    assert sp > 0 and warm == 30 and b.last_kernel in ("wide", "quad")      # (a segment instance of either form: by predicted time)
     op = O.InputParams.from_dict(pd)
     lens = np.array([len(u) for u in utt])
     order = np.argsort(lens)
