@@ -385,7 +385,9 @@ int  trm_batch_last_kernel(const trm_batch *batch);
  * whatever the machine.  But the tube forgets: every travelling wave is multiplied by dampingFactor = 1 - lossFactor/100
  * once per sample (:216), the end filters, throat and frication band-pass are stable filters, the oscillator FIR and the
  * converter are feed-forward, the noise is a fixed sequence and the oscillator position an exact prefix sum.  A time-split
- * launch cuts every utterance into segments of `periods` control periods and runs them side by side, each from rest a
+ * launch cuts every utterance into segments of `periods` control periods (the first one a warm-up longer) and runs them side
+ * by side -- a workgroup is one segment of 64 voices in the one-voice-per-lane form, of 16 in the four-lane form (small
+ * batches, a single utterance: 1 s of speech in 0.6 ms); trm_batch_last_kernel names the form -- each from rest a
  * warm-up ahead of its first period; the warm-up is chosen by the library so that 1e-5 of the forgotten state is left
  * (damping^W <= 1e-5: 30 control periods at Monet's defaults; measured against the oracle in tools/timesplit_study.py
  * and by the parity tests at the one tolerance, 1e-5).  numberSamples and the sample positions are exact as always.
