@@ -60,6 +60,7 @@ EXPORTS = [
     "trm_batch_create", "trm_batch_destroy", "trm_batch_derived", "trm_batch_samples_for_frames",
     "trm_derive", "trm_samples_for_frames",
     "trm_batch_synthesize_host", "trm_batch_synthesize_host_int16", "trm_batch_synthesize_device", "trm_batch_scale_to_int16_device",
+    "trm_sound_file_size", "trm_batch_sound_files_device",
     "trm_shard_voices", "trm_multi_create", "trm_multi_destroy", "trm_multi_synthesize_host", "trm_multi_synthesize_host_int16",
     "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
     "trm_stream_push", "trm_stream_finish", "trm_stream_set_mode", "trm_stream_mode", "trm_stream_set_slice", "trm_stream_slice", "trm_stream_push_device", "trm_stream_finish_device", "trm_stream_kernel",
@@ -132,6 +133,9 @@ def lib():
     L.trm_multi_synthesize_host_int16.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.trm_batch_synthesize_device.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp]
     L.trm_batch_scale_to_int16_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.trm_sound_file_size.argtypes = [C.POINTER(TrmInputParams), C.c_size_t]
+    L.trm_sound_file_size.restype = C.c_size_t
+    L.trm_batch_sound_files_device.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.trm_batch_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.trm_stream_create.argtypes = [C.POINTER(TrmInputParams), C.c_int, C.c_size_t, C.POINTER(vp)]
     L.trm_stream_destroy.argtypes = [vp]

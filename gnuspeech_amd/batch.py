@@ -188,6 +188,23 @@ class TRMBatch:
             st["max_sample"].data_ptr(), pcm16.data_ptr(), int(for_wav_data), C.c_void_p(s.cuda_stream)))
         return pcm16
 
+    def sound_files_device(self, st, stream=None):
+        """The batch's sound files composed on the device (trm_batch_sound_files_device): returns (uint8 CUDA tensor holding
+        every voice's file image -- header + int16 payload in the container's byte order --, byte offsets, sizes)."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        sizes = np.array([lib().trm_sound_file_size(C.byref(self.inputParameters.c), int(n)) for n in st["nout"]], dtype=np.int64)
+        pitch = (sizes + 63) // 64 * 64
+        foff = np.zeros(max(1, st["V"]), dtype=np.int64)
+        if st["V"] > 1:
+            foff[1:st["V"]] = np.cumsum(pitch[:-1])
+        files = torch.zeros(max(1, int(pitch.sum())), dtype=torch.uint8, device=st["out"].device)
+        d_foff = torch.from_numpy(foff).to(st["out"].device)
+        check(lib().trm_batch_sound_files_device(
+            self._h, st["V"], st["out"].data_ptr(), st["out_offset"].data_ptr(), st["number_samples"].data_ptr(),
+            st["max_sample"].data_ptr(), files.data_ptr(), d_foff.data_ptr(), C.c_void_p(s.cuda_stream)))
+        return files, foff, sizes
+
     def noise_table(self, n):
         out = np.zeros(int(n), dtype=np.float32)
         check(lib().trm_batch_noise_table(self._h, out.ctypes.data, int(n)))
@@ -272,5 +289,6 @@ class TRMMultiBatch(TRMBatch):
         raise NotImplementedError("TRMMultiBatch carries the host-buffer entries only (one trm_batch per device inside the library)")
 
     prepare_device = synthesize_device = scale_to_int16_device = prepare_events_device = generate_frames_device = _device_only
+    sound_files_device = _device_only
     noise_table = set_kernel = kernel_time_ms = set_timing = set_time_split = _device_only
     last_kernel = last_time_split = property(_device_only)

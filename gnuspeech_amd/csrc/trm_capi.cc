@@ -1508,6 +1508,41 @@ int trm_batch_scale_to_int16_device(trm_batch *b, size_t nvoices, const float *d
     return TRM_OK;
 }
 
+size_t trm_sound_file_size(const trm_input_params *params, size_t nsamples)
+{
+    if (!params) return 0;
+    uint8_t hdr[56];
+    const size_t h = trm::io_sound_file_header(*params, nsamples, hdr);
+    return h ? h + nsamples * (params->channels == 2 ? 2 : 1) * 2 : 0;
+}
+
+int trm_batch_sound_files_device(trm_batch *b, size_t nvoices, const float *d_pcm, const uint64_t *d_out_offset,
+                                 const uint32_t *d_number_samples, const float *d_max_sample, uint8_t *d_files,
+                                 const uint64_t *d_file_offset, void *stream_)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (nvoices == 0) return TRM_OK;
+    if (!d_pcm || !d_out_offset || !d_number_samples || !d_max_sample || !d_files || !d_file_offset) return fail(TRM_EINVAL, "null device pointer");
+    HIP_TRY(hipSetDevice(b->device));
+    trm::FileArgs f;
+    f.s.pcm = d_pcm;
+    f.s.out_offset = d_out_offset;
+    f.s.number_samples = d_number_samples;
+    f.s.max_sample = d_max_sample;
+    f.s.pcm16 = nullptr;
+    f.s.volumeAmp = trm::io_amplitude(b->params.volume);
+    f.s.balance = b->params.balance;
+    f.s.channels = b->params.channels;
+    f.s.forWavData = 0;
+    f.files = d_files;
+    f.file_offset = d_file_offset;
+    f.format = b->params.outputFileFormat;
+    memset(f.header, 0, sizeof f.header);
+    if (trm::io_sound_file_header(b->params, 0, f.header) == 0) return fail(TRM_EINVAL, "unknown sound file format %d", (int)b->params.outputFileFormat);
+    HIP_TRY(trm::launch_file_images(f, (uint32_t)nvoices, (hipStream_t)stream_));
+    return TRM_OK;
+}
+
 // ------------------------------------------------------------------ TRMTubeModel
 int trm_tube_create(const trm_input_params *params, int device, trm_tube **out)
 {

@@ -148,30 +148,23 @@ void ext80(uint8_t *b, double v)
 
 }  // namespace
 
-int io_write_sound_file(const char *path, const trm_input_params &p, const float *s, size_t n, double maxSample)
+// the container's header for `n` samples (TRMTubeModel.m:414-487 through AudioToolbox in the reference; byte layouts of the
+// three formats as this library writes them); returns its length, 0 for an unknown format
+size_t io_sound_file_header(const trm_input_params &p, size_t n, uint8_t *hdr)
 {
-    int ch = p.channels == 2 ? 2 : 1;
-    std::vector<int16_t> pcm(n * ch + 1);
-    io_scale_int16(p, s, n, maxSample, false, pcm.data());
-    size_t bytes = n * ch * 2;
-    std::vector<uint8_t> body(bytes);
-    bool little = p.outputFileFormat == TRM_SOUND_FILE_FORMAT_WAVE;     // :410-412
-    for (size_t i = 0; i < n * ch; i++) {
-        if (little) le16(&body[2 * i], (uint16_t)pcm[i]);
-        else be16(&body[2 * i], (uint16_t)pcm[i]);
-    }
-    std::vector<uint8_t> hdr;
-    uint32_t rate = (uint32_t)p.outputRate;
+    const int ch = p.channels == 2 ? 2 : 1;
+    const size_t bytes = n * ch * 2;
+    const uint32_t rate = (uint32_t)p.outputRate;
     if (p.outputFileFormat == TRM_SOUND_FILE_FORMAT_AU) {
-        hdr.resize(24);
         be32(&hdr[0], 0x2e736e64);               // ".snd"
         be32(&hdr[4], 24);
         be32(&hdr[8], (uint32_t)bytes);
         be32(&hdr[12], 3);                       // 16-bit linear PCM
         be32(&hdr[16], rate);
         be32(&hdr[20], (uint32_t)ch);
-    } else if (p.outputFileFormat == TRM_SOUND_FILE_FORMAT_AIFF) {
-        hdr.resize(54);
+        return 24;
+    }
+    if (p.outputFileFormat == TRM_SOUND_FILE_FORMAT_AIFF) {
         memcpy(&hdr[0], "FORM", 4);
         be32(&hdr[4], (uint32_t)(4 + 8 + 18 + 8 + 8 + bytes));
         memcpy(&hdr[8], "AIFF", 4);
@@ -185,8 +178,9 @@ int io_write_sound_file(const char *path, const trm_input_params &p, const float
         be32(&hdr[42], (uint32_t)(8 + bytes));
         be32(&hdr[46], 0);
         be32(&hdr[50], 0);
-    } else if (p.outputFileFormat == TRM_SOUND_FILE_FORMAT_WAVE) {
-        hdr.resize(44);
+        return 54;
+    }
+    if (p.outputFileFormat == TRM_SOUND_FILE_FORMAT_WAVE) {
         memcpy(&hdr[0], "RIFF", 4);
         le32(&hdr[4], (uint32_t)(36 + bytes));
         memcpy(&hdr[8], "WAVEfmt ", 8);
@@ -199,8 +193,26 @@ int io_write_sound_file(const char *path, const trm_input_params &p, const float
         le16(&hdr[34], 16);
         memcpy(&hdr[36], "data", 4);
         le32(&hdr[40], (uint32_t)bytes);
-    } else
-        return TRM_EINVAL;
+        return 44;
+    }
+    return 0;
+}
+
+int io_write_sound_file(const char *path, const trm_input_params &p, const float *s, size_t n, double maxSample)
+{
+    int ch = p.channels == 2 ? 2 : 1;
+    std::vector<int16_t> pcm(n * ch + 1);
+    io_scale_int16(p, s, n, maxSample, false, pcm.data());
+    size_t bytes = n * ch * 2;
+    std::vector<uint8_t> body(bytes);
+    bool little = p.outputFileFormat == TRM_SOUND_FILE_FORMAT_WAVE;     // :410-412
+    for (size_t i = 0; i < n * ch; i++) {
+        if (little) le16(&body[2 * i], (uint16_t)pcm[i]);
+        else be16(&body[2 * i], (uint16_t)pcm[i]);
+    }
+    std::vector<uint8_t> hdr(56);
+    hdr.resize(io_sound_file_header(p, n, hdr.data()));
+    if (hdr.empty()) return TRM_EINVAL;
     FILE *fp = fopen(path, "wb");
     if (!fp) return TRM_EIO;
     bool ok = fwrite(hdr.data(), 1, hdr.size(), fp) == hdr.size() && (bytes == 0 || fwrite(body.data(), 1, bytes, fp) == bytes);

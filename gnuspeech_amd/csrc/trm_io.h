@@ -22,6 +22,8 @@ int io_write_data_list(const char *path, const trm_input_params &p, const trm_pa
 void io_scale_int16(const trm_input_params &p, const float *samples, size_t n, double maxSample,
                     bool forWavData, int16_t *out);
 
+// the container's header for n samples into hdr[>= 56]; returns its length (0: unknown format)
+size_t io_sound_file_header(const trm_input_params &p, size_t n, uint8_t *hdr);
 // -saveOutputToFile:error: (TRMTubeModel.m:365-490): AU / AIFF big-endian, WAVE little-endian.
 int io_write_sound_file(const char *path, const trm_input_params &p, const float *samples, size_t n, double maxSample);
 

@@ -130,6 +130,15 @@ struct DownArgs {
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
+// sound-file images (header + int16 payload in the container's byte order) per voice, on the device
+struct FileArgs {
+    ScaleArgs s;                  // (pcm16 unused)
+    uint8_t *files;
+    const uint64_t *file_offset;  // byte offset of voice v's image
+    int32_t format;               // TRM_SOUND_FILE_FORMAT_AU / _AIFF / _WAVE
+    uint8_t header[56];           // the container's header with its size fields left 0 (trm_io.cc: io_sound_file_header)
+};
+hipError_t launch_file_images(const FileArgs &f, uint32_t nvoices, hipStream_t stream);
 // out[v * pitch + i] *= g (i < count), mx[v] *= g
 hipError_t launch_gain(float *out, size_t pitch, uint32_t count, uint32_t nvoices, float *mx, float g, hipStream_t stream);
 

@@ -930,6 +930,51 @@ __global__ __launch_bounds__(256) void trm_int16_kernel(const ScaleArgs S)
     }
 }
 
+// Sound-file images on the device: -saveOutputToFile:error: (TRMTubeModel.m:365-490) for every voice of a batch --
+// the container's header (AU 24 bytes, AIFF 54, WAVE 44; the byte layouts of csrc/trm_io.cc's host writer) followed by the
+// int16 payload in the container's byte order (AU / AIFF big-endian, WAVE little-endian, :410-412), scaled like
+// trm_int16_kernel's file form (x2 stereo gains, :382-383) -- at files + file_offset[v]: one D2H, or a write() straight from a
+// mapped buffer, gives ready files.  One workgroup per voice.
+__global__ __launch_bounds__(256) void trm_file_image_kernel(const FileArgs F)
+{
+    const uint32_t v = blockIdx.x;
+    const uint32_t n = F.s.number_samples[v];
+    const float mx = F.s.max_sample[v];
+    const float *src = F.s.pcm + F.s.out_offset[v];
+    uint8_t *img = F.files + F.file_offset[v];
+    const uint32_t ch = F.s.channels == 2 ? 2u : 1u, bytes = n * ch * 2u;
+    const uint32_t hdr = F.format == 0 ? 24u : F.format == 1 ? 54u : 44u;
+    if (threadIdx.x < hdr) {
+        // header byte i: fixed bytes from the host's template (magic words, rate, channel count, the AIFF rate as an 80-bit
+        // extended), the size fields filled in here (they depend on the voice's sample count)
+        const uint32_t i = threadIdx.x;
+        uint8_t b = F.header[i];
+        auto be = [&](uint32_t at, uint32_t val) { if (i >= at && i < at + 4) b = (uint8_t)(val >> (8 * (3 - (i - at)))); };
+        auto le = [&](uint32_t at, uint32_t val) { if (i >= at && i < at + 4) b = (uint8_t)(val >> (8 * (i - at))); };
+        if (F.format == 0) be(8, bytes);
+        else if (F.format == 1) { be(4, 4 + 8 + 18 + 8 + 8 + bytes); be(22, n); be(42, 8 + bytes); }
+        else { le(4, 36 + bytes); le(40, bytes); }
+        img[i] = b;
+    }
+    const double scale = (32767.0 / (double)mx) * F.s.volumeAmp;
+    const double left = ch == 2 ? -((F.s.balance / 2.0) - 0.5) * scale * 2.0 : scale;
+    const double right = ((F.s.balance / 2.0) + 0.5) * scale * 2.0;
+    const bool big = F.format != 2;
+    uint8_t *body = img + hdr;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = (double)src[i];
+        uint16_t a = (uint16_t)(int64_t)__builtin_rint(x * left);              // wraps like the reference's x86 cast
+        if (big) a = (uint16_t)((a << 8) | (a >> 8));
+        if (ch == 2) {
+            uint16_t r = (uint16_t)(int64_t)__builtin_rint(x * right);
+            if (big) r = (uint16_t)((r << 8) | (r >> 8));
+            body[4 * i] = (uint8_t)a; body[4 * i + 1] = (uint8_t)(a >> 8); body[4 * i + 2] = (uint8_t)r; body[4 * i + 3] = (uint8_t)(r >> 8);
+        } else {
+            body[2 * i] = (uint8_t)a; body[2 * i + 1] = (uint8_t)(a >> 8);
+        }
+    }
+}
+
 // out[v * pitch + i] *= g for i < count; mx[v] *= g  (streams in TRAcT's loop order: tube.c:1177's x100)
 __global__ __launch_bounds__(256) void trm_gain_kernel(float *out, size_t pitch, uint32_t count, uint32_t nvoices, float *mx, float g)
 {
@@ -1023,6 +1068,13 @@ hipError_t launch_gain(float *out, size_t pitch, uint32_t count, uint32_t nvoice
     if (nvoices == 0 || count == 0) return hipSuccess;
     hipLaunchKernelGGL(trm_gain_kernel, dim3((count + 255) / 256, nvoices < 32768u ? nvoices : 32768u), dim3(256), 0, stream, out, pitch, count,
                        nvoices, mx, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_file_images(const FileArgs &f, uint32_t nvoices, hipStream_t stream)
+{
+    if (nvoices == 0) return hipSuccess;
+    hipLaunchKernelGGL(trm_file_image_kernel, dim3(nvoices), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
 

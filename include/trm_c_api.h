@@ -228,6 +228,16 @@ int  trm_batch_scale_to_int16_device(trm_batch *batch, size_t nvoices,
                                      const uint32_t *d_number_samples, const float *d_max_sample,
                                      int16_t *d_int16, int for_wav_data, void *stream);
 
+/* Sound files composed on the device: for every voice the complete file image -- the container's header
+ * (params->outputFileFormat: AU 24 bytes, AIFF 54, WAVE 44) followed by the int16 payload in the container's byte order, scaled
+ * as -saveOutputToFile:error: scales it (TRMTubeModel.m:370-389) -- at d_files + d_file_offset[v] (bytes).  An image is
+ * trm_sound_file_size(params, numberSamples) bytes: byte for byte what trm_write_sound_file writes for the same samples.  One
+ * copy (or a write() from a mapped buffer) then gives ready files; nothing but finished containers crosses PCIe. */
+size_t trm_sound_file_size(const trm_input_params *params, size_t nsamples);
+int  trm_batch_sound_files_device(trm_batch *batch, size_t nvoices, const float *d_pcm, const uint64_t *d_out_offset,
+                                  const uint32_t *d_number_samples, const float *d_max_sample, uint8_t *d_files,
+                                  const uint64_t *d_file_offset, void *stream);
+
 /* -saveOutputToFile:error: (TRMTubeModel.m:365-490) for one voice of a batch: writes `n` fp32 samples
  * with their maximumSampleValue as the AU / AIFF / WAVE file params->outputFileFormat names (int16, the
  * reference's scale, balance and byte order).  Host-side container code; the samples come from

@@ -774,6 +774,39 @@ def test_hip_graph_capture_and_replay(g, form, rate):
     b.set_timing(True)
 
 
+@pytest.mark.parametrize("fmt", [0, 1, 2])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_sound_files_composed_on_the_device(g, tmp_path, fmt, channels):
+    """SURVEY 8f N2 "containers on device": trm_batch_sound_files_device writes every voice's complete file image -- header +
+    int16 payload in the container's byte order -- on the GPU; byte for byte what the host writer (trm_write_sound_file =
+    -saveOutputToFile:error:, TRMTubeModel.m:365-490) writes for the same samples: AU / AIFF / WAVE, mono / stereo, ragged voices
+    incl. one of two frames."""
+    import ctypes as C
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    pd.update(outputFileFormat=fmt, channels=channels, balance=0.3, volume=57.0)
+    ip = g.TRMInputParameters.from_dict(pd)
+    voices = cases.config4_frames(9, lo=5, hi=40) + [cases.load_gnuspeech_rows()[3:5].copy()]
+    b = g.TRMBatch(ip)
+    st = b.prepare_device(voices)
+    b.synthesize_device(st)
+    files, foff, sizes = b.sound_files_device(st)
+    torch.cuda.synchronize()
+    img = files.cpu().numpy()
+    out = st["out"].cpu().numpy()
+    ns = st["number_samples"].cpu().numpy()
+    mx = st["max_sample"].cpu().numpy()
+    for v in range(len(voices)):
+        n = int(ns[v])
+        assert int(sizes[v]) == g.lib().trm_sound_file_size(C.byref(ip.c), n)
+        samples = np.ascontiguousarray(out[int(st["out_offset_host"][v]):int(st["out_offset_host"][v]) + n])
+        path = str(tmp_path / ("v%d" % v)).encode()
+        assert g.lib().trm_write_sound_file(C.byref(ip.c), samples.ctypes.data, n, float(mx[v]), path) == 0
+        want = np.fromfile(path.decode(), dtype=np.uint8)
+        got = img[int(foff[v]):int(foff[v]) + int(sizes[v])]
+        assert got.size == want.size and np.array_equal(got, want), (fmt, channels, v)
+
+
 def test_full_size_properties(g, form):
     """BASELINE config 2 at full size (4096 voices x 1 s): size-independent properties -- exact sample
     counts, finite output, voices with identical tracks give identical bits wherever they sit in the
