@@ -96,9 +96,6 @@ struct ScaleArgs {
 int tube_kernel_blocks_per_cu();
 hipError_t launch_noise(float *lp, uint32_t from, uint32_t to, double *state, hipStream_t stream);
 hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream);
-// one wave per workgroup, every stage in it (trm_solo.hip): one-shot and time-split launches
-hipError_t launch_tube_solo(const Const &c, const TubeArgs &a, hipStream_t stream);
-int tube_solo_kernel_blocks_per_cu();
 // small-batch form (trm_quad.hip): 16 voices per workgroup, four lanes per voice
 constexpr int kStreamFloats = 192;   // oscillator position, filter memories, 32 samples of FIR / converter history, 4 x 20 tube values
 // `cus` = the device's compute units: more workgroups than that run the instance that fits two per CU

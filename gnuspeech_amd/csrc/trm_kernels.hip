@@ -13,7 +13,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <string.h>
 
 #include <type_traits>
 
@@ -1000,8 +999,6 @@ hipError_t launch_tube(const Const &c, const TubeArgs &a, hipStream_t stream)
     if (a.nvoices == 0) return hipSuccess;
     // (time-split: one workgroup per segment and block of 64 voices; seg_wg_per_seg * segments, set by the caller in wg_base's
     // place holder `seg_grid`)
-    static const bool solo = [] { const char *e = getenv("TRM_WIDE_IMPL"); return e && !strcmp(e, "solo"); }();
-    if (solo && !a.stream_state) return launch_tube_solo(c, a, stream);
     const uint32_t grid = a.seg_periods ? a.seg_grid : (a.nvoices + kWave - 1) / kWave;
     // A grid of more than two rounds of resident workgroups (2 per CU) runs measurably slower per workgroup than its first
     // two rounds (MI355X, 256 CUs: 1024 workgroups 18.1 ms, 1536: 32.6, 2048: 40.6 -- profiles/ab_r03.txt): the

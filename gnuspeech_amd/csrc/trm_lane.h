@@ -344,15 +344,6 @@ TRM_HD Excitation mix_sample(FirState &S, const Const &C, const float *fir, cons
     return mix_tail(C, O.ax, O.ah1, pulse, lpNoise);
 }
 
-// The same with the 49 taps spelled out (`taps[i]` = tap i, e.g. in LDS: no register holds a tap beyond its use).
-TRM_HD Excitation mix_sample_unfolded(FirState &S, const Const &C, const float *taps, const OscOut &O, float lpNoise)
-{
-    float pulse = fma_f(taps[0], O.wb, fma_f(taps[1], O.wa, S.fir[0]));
-    for (int q = 0; q < 23; q++) S.fir[q] = fma_f(taps[2 * q + 2], O.wb, fma_new_f(taps[2 * q + 3], O.wa, S.fir[q + 1]));
-    S.fir[23] = taps[48] * O.wb;
-    return mix_tail(C, O.ax, O.ah1, pulse, lpNoise);
-}
-
 // Both halves in one call (host emulation).
 template <class SineLookup>
 TRM_HD Excitation excite_sample(ExciteState &S, ExciteTrack &T, const Const &C, const float *fir, int j, float lpNoise,
