@@ -4,6 +4,7 @@ Tolerance (BASELINE.json north_star): RMS error <= 1e-5 on output normalised by 
 maximumSampleValue; numberSamples must match exactly.  The HIP path computes the signal in fp32
 (fp64 only at the reference's discontinuities), so agreement is a tolerance, not bit-equality.
 """
+import os
 import re
 
 import numpy as np
@@ -964,3 +965,16 @@ def test_full_size_configs4_per_gpu_batch(g, split):
     for v in (0, 4097, 8190):
         o = O.synthesize(op, fr[v].astype(np.float32).astype(np.float64))
         assert nrms(out[v], o["samples"], o["maximumSampleValue"]) <= RMS_TOL
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs():
+    """the driver's round-end check: __graft_entry__.smoke() (one small batch through every kernel form and a time-split launch,
+    against the oracle) must keep passing as the forms change"""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
