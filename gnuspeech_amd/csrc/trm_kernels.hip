@@ -292,6 +292,8 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
         };
         FirState S;
         for (int i = 0; i < 24; i++) S.fir[i] = (kStream && !sFirst) ? st[2 + i] : 0.f;
+        // the throat's one-pole low-pass runs here (tube_step<., kThroatDone>): it sees the excitation only
+        float throatY = (kStream && !sFirst) ? st[64] : 0.f;
         // The 25 distinct FIR taps live in VGPRs of this wave (uniform values): as SGPRs they would
         // exceed the scalar file together with the other constants and be spilled to VGPR lanes.
         float firv[kFirUnique];
@@ -319,9 +321,12 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
                         OscOut O;
                         O.wa = w.x; O.wb = w.y; O.ax = w.z; O.ah1 = w.w;
                         Excitation E = mix_sample(S, C, firv, O, sNoise[n & (kNoiseRing - 1)]);
-                        if (kStream && n + 1u == ntubeLane && laneValid)
+                        throatY = throat_filter(throatY, C.ta0, C.tb1, E.thr);
+                        if (kStream && n + 1u == ntubeLane && laneValid) {
                             for (int i = 0; i < 24; i++) st[2 + i] = S.fir[i];
-                        sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, E.thr, 0.0f);
+                            st[64] = throatY;
+                        }
+                        sX[(buf * kTB + u) * kWave + lane] = make_float4(E.gin, E.sig, throatY, 0.0f);
                     }
                 }
             }
@@ -391,20 +396,22 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             for (int i = 0; i < 10; i++) { wA.oT[i] = st[26 + i]; wA.oB[i] = st[36 + i]; }
             for (int i = 0; i < 6; i++) { wA.nT[i] = st[46 + i]; wA.nB[i] = st[52 + i]; }
             F.mReflY = st[58]; F.mRadX = st[59]; F.mRadY = st[60]; F.nReflY = st[61]; F.nRadX = st[62]; F.nRadY = st[63];
-            F.throatY = st[64]; F.bpX1 = st[65]; F.bpX2 = st[66]; F.bpY1 = st[67]; F.bpY2 = st[68];
+            F.bpX1 = st[65]; F.bpX2 = st[66]; F.bpY1 = st[67]; F.bpY2 = st[68];       // (st[64], the throat's memory: the mix wave)
         }
         // the step's constants as vector registers (tube_step): opaque moves, so that the compiler cannot go back to the
         // kernel arguments' scalar registers.  (With the other round-3 changes 18.2 ms against 18.5 ms for the saturating
         // batch, profiles/ab_r03.txt; on the round-2 kernel alone the same change measured 1 % slower.)
         TubeConst TC;
-        float mA10v;
+        float mA10v, negMA10v;
         {
             auto vcopy = [](float s) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s)); return r; };
             TC.damping = vcopy(C.damping); TC.mCoeff = vcopy(C.mCoeff); TC.nCoeff = vcopy(C.nCoeff);
             for (int i = 0; i < 4; i++) TC.nasalTd[i] = vcopy(C.nasalTd[i]);
             TC.nasalK6a = vcopy(C.nasalK6a); TC.onePlusNK6 = vcopy(C.onePlusNK6);
-            TC.ta0 = vcopy(C.ta0); TC.tb1 = vcopy(C.tb1); TC.throatGain = vcopy(C.throatGain);
+            TC.ta0 = TC.tb1 = 0.0f;        // (the throat section runs in the mix wave)
+            TC.throatGain = vcopy(C.throatGain);
             mA10v = vcopy(C.mA10);
+            negMA10v = vcopy(-C.mA10);
         }
         float *const ring = &sY[lane * kYStride];
         // down-sampling batches: tube-rate samples (and the zero flush) go to HBM for trm_downsample_kernel
@@ -419,19 +426,19 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
             Coefs K;
             K.td[0] = k0.x; K.td[1] = k0.y; K.td[2] = k0.z; K.td[3] = k0.w;
             K.td[4] = k1.x; K.td[5] = k1.y; K.td[6] = k1.z; K.onePlusK8 = k1.w;
-            K.k8a = (K.onePlusK8 - 1.0f) * mA10v;        // C8 a10 (C8 is near -1 when the mouth closes: no cancellation here)
+            K.k8a = fma_f(K.onePlusK8, mA10v, negMA10v); // C8 a10 = (1 + C8) a10 - a10 in one operation (C8 is near -1 when the mouth closes: no cancellation here)
             K.alphaU = k2.x; K.ntd1 = k2.y; K.bpBeta = k2.z; K.bpGamma = k2.w;
             K.alphaLR = fma_f(-0.5f, K.alphaU, 1.0f);    // the three alphas sum to 2 (TRMTubeModel.m:733-736)
-            K.bpAlpha = (0.5f - K.bpBeta) * 0.5f;        // TRMFilters.m:16
+            K.bpAlpha = fma_f(-0.5f, K.bpBeta, 0.25f);   // (1/2 - beta) / 2, TRMFilters.m:16 (the halving is exact: the same bits in one operation)
             K.tap[0] = t0.x; K.tap[1] = t0.y; K.tap[2] = t0.z; K.tap[3] = t0.w;
             K.tap[4] = t1.x; K.tap[5] = t1.y; K.tap[6] = t1.z; K.tap[7] = t1.w;
             K.pad_ = 0.0f;
-            float y = tube_step(o, nw, F, TC, E, K);
+            float y = tube_step<TubeConst, true>(o, nw, F, TC, E, K);
             if (kStream && n + 1u == ntubeLane && laneValid) {       // the chunk's last sample: what the next chunk starts from
                 for (int i = 0; i < 10; i++) { st[26 + i] = nw.oT[i]; st[36 + i] = nw.oB[i]; }
                 for (int i = 0; i < 6; i++) { st[46 + i] = nw.nT[i]; st[52 + i] = nw.nB[i]; }
                 st[58] = F.mReflY; st[59] = F.mRadX; st[60] = F.mRadY; st[61] = F.nReflY; st[62] = F.nRadX; st[63] = F.nRadY;
-                st[64] = F.throatY; st[65] = F.bpX1; st[66] = F.bpX2; st[67] = F.bpY1; st[68] = F.bpY2;
+                st[65] = F.bpX1; st[66] = F.bpX2; st[67] = F.bpY1; st[68] = F.bpY2;
             }
             y = n < ntubeLane ? y : 0.0f;      // zero flush / voices shorter than the group's longest
             // converter position of tube sample n is n + 25 (25 zeros of pre-roll); a chunk's sample n is the

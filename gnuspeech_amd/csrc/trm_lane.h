@@ -525,6 +525,9 @@ TRM_HD void tube_reset(TubeState &S)
     filters_reset(S.f);
 }
 
+// throat low-pass (:341, TRMFilters.m:72-77): y = ta0 x + tb1 y1
+TRM_HD float throat_filter(float y1, float ta0, float tb1, float x) { return fma_f(ta0, x, tb1 * y1); }
+
 // One sample: old waves `o` -> new waves `nw` (all new values from old values only, :778-853).
 // Returns the tube-rate output sample (what the reference hands to -dataFill:, :346).
 // CT: where the step's wave-uniform constants come from -- `Const` itself (kernel arguments: scalar registers) or a
@@ -535,7 +538,10 @@ struct TubeConst {
     float damping, mCoeff, nCoeff, nasalTd[4], nasalK6a, onePlusNK6, ta0, tb1, throatGain;
 };
 
-template <class CT>
+// kThroatDone: E.thr already IS the throat filter's output (the one-voice-per-lane kernel runs that one-pole section, which
+// depends on the excitation alone, in its mixing wave: two instructions off the wave every step waits for; same operations,
+// same bits).
+template <class CT, bool kThroatDone = false>
 TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const CT &C, const Excitation &E, const Coefs &K)
 {
     // frication band-pass (TRMFilters.m:19-29), evaluated before the tract (:336-337)
@@ -602,8 +608,11 @@ TRM_HD float tube_step(const Waves &o, Waves &nw, TubeFilters &L, const CT &C, c
         out += rad;
     }
     // throat (:341, TRMFilters.m:72-77)
-    wg_t ty = fma_f((wg_t)C.ta0, (wg_t)E.thr, C.tb1 * L.throatY);
-    L.throatY = ty;
+    wg_t ty = (wg_t)E.thr;
+    if (!kThroatDone) {
+        ty = throat_filter(L.throatY, C.ta0, C.tb1, E.thr);
+        L.throatY = ty;
+    }
     out = ty * C.throatGain + out;
     return (float)out;
 }

@@ -230,7 +230,8 @@ def test_split_equals_whole_to_rounding_and_is_deterministic(g):
     for v in range(70):
         assert np.array_equal(p1[v], p2[v])
         m = float(mxa[v])
-        assert np.abs(p1[v].astype(np.float64) - a[v]).max() / m < 1e-5
+        # (worst single sample; a nearly silent voice -- peak below 1e-3 -- is fp32 rounding noise in both launches: absolute floor)
+        assert np.abs(p1[v].astype(np.float64) - a[v]).max() < max(1e-5 * m, 2e-8), v
         assert nrms(p1[v], a[v].astype(np.float64), m) < 2e-6
     assert np.array_equal(mx1, mx2)
 
