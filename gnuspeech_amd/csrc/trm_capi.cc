@@ -748,7 +748,8 @@ int trm_stream_create(const trm_input_params *params, int device, size_t nvoices
     trm_batch *b = nullptr;
     int rc = trm_batch_create(params, device, &b);
     if (rc) return rc;
-    if (!b->c.upsample && (!b->dDownRows || b->downR > (uint32_t)b->d.padSize || b->downL > (uint32_t)b->d.padSize + 1u)) {
+    if (!b->c.upsample && (!b->dDownRows || b->downR > (uint32_t)b->d.padSize || b->downL > (uint32_t)b->d.padSize + 1u ||
+                           !trm::downsample_tiled_fits(b->c, b->downL, b->downR))) {
         // (a chunk emits the outputs whose read position lies inside it; their right wing must end there too)
         trm_batch_destroy(b);
         return fail(TRM_ERANGE, "streaming: output rate too far below the tube rate (%d Hz) for the tiled down-sampling kernel", b->d.sampleRate);

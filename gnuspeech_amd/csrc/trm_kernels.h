@@ -129,6 +129,8 @@ struct DownArgs {
     uint32_t ntiles = 0;          // tiled kernel: time tiles of the launch (set by launch_downsample)
 };
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream);
+// whether the tiled kernel (the only one that converts stream chunks) can run a converter of lmax + rmax taps
+bool downsample_tiled_fits(const Const &c, uint32_t lmax, uint32_t rmax);
 hipError_t launch_int16(const ScaleArgs &s, uint32_t nvoices, hipStream_t stream);
 // sound-file images (header + int16 payload in the container's byte order) per voice, on the device
 struct FileArgs {

@@ -1044,14 +1044,34 @@ int tube_kernel_blocks_per_cu()
     return n;
 }
 
+// LDS of the tiled down-sampling kernel for a converter of lmax + rmax taps: 64 coefficient rows + 32 voices' windows
+static size_t down_tile_lds(const Const &c, uint32_t lmax, uint32_t rmax, uint32_t *xlenOut)
+{
+    const uint32_t T = lmax + rmax;
+    const uint32_t xlen = (uint32_t)(((uint64_t)(kDownCols - 1) * c.timeRegisterIncrement) >> 16) + 2u + T;
+    if (xlenOut) *xlenOut = xlen;
+    return ((size_t)kDownCols * (T | 1u) + (size_t)kDownVoices * xlen) * sizeof(float);
+}
+// up to 48 KB (three workgroups per CU) at speech-rate ratios; the widest converter a stream accepts (output at a quarter of the
+// tube rate) needs 73 KB
+constexpr size_t kDownLdsMax = 96 * 1024;
+bool downsample_tiled_fits(const Const &c, uint32_t lmax, uint32_t rmax)
+{
+    return lmax + rmax > 0 && down_tile_lds(c, lmax, rmax, nullptr) <= kDownLdsMax;
+}
+
 hipError_t launch_downsample(const Const &c, const DownArgs &a, hipStream_t stream)
 {
     if (a.nvoices == 0) return hipSuccess;
-    // the tiled kernel where its rows and windows fit LDS comfortably (any speech-rate ratio does), else the generic walk
-    const uint32_t T = a.lmax + a.rmax;
-    const uint32_t xlen = (uint32_t)(((uint64_t)(kDownCols - 1) * c.timeRegisterIncrement) >> 16) + 2u + T;
-    const size_t lds = ((size_t)kDownCols * (T | 1u) + (size_t)kDownVoices * xlen) * sizeof(float);
-    if (a.rows && T > 0 && lds <= 48 * 1024) {
+    // the tiled kernel where its rows and windows fit LDS (any ratio a stream accepts does), else the generic walk
+    uint32_t xlen = 0;
+    const size_t lds = down_tile_lds(c, a.lmax, a.rmax, &xlen);
+    if (a.rows && downsample_tiled_fits(c, a.lmax, a.rmax)) {
+        if (lds > 48 * 1024) {
+            static DynamicLdsAllowance allowance;
+            hipError_t ea = allowance.ensure(reinterpret_cast<const void *>(trm_downsample_rows_kernel), (int)kDownLdsMax);
+            if (ea != hipSuccess) return ea;
+        }
         const uint32_t ntubeMax = a.max_nframes > 0 ? (a.max_nframes - 1) * (uint32_t)c.controlPeriod : 0;
         // (a shorter voice may end on the reference's extra lap, src_count_outputs: cover it)
         uint64_t noutMax = (((uint64_t)ntubeMax + 2ull * (uint32_t)c.padSize + kSrcRing) * 65536ull + c.timeRegisterIncrement - 1) / c.timeRegisterIncrement;

@@ -77,13 +77,17 @@ def test_chunked_equals_one_shot(g, rate, chunks):
     assert np.allclose(got_max, mx, rtol=1e-4)
 
 
-@pytest.mark.parametrize("rate,chunks", [(16000.0, [5, 1, 1, 17, 2, 30, 4]), (8000.0, [60]), (16000.0, [1] * 12 + [48]),
-                                          (11025.0, [2, 58]), (8000.0, [3, 3, 1, 40, 13])])
-def test_chunked_equals_one_shot_downsampling(g, rate, chunks):
+@pytest.mark.parametrize("rate,chunks,length", [(16000.0, [5, 1, 1, 17, 2, 30, 4], None), (8000.0, [60], None), (16000.0, [1] * 12 + [48], None),
+                                                 (11025.0, [2, 58], None), (8000.0, [3, 3, 1, 40, 13], None),
+                                                 (8000.0, [7, 1, 30, 22], 13.79), (8000.0, [60], 12.2)])
+def test_chunked_equals_one_shot_downsampling(g, rate, chunks, length):
     """The same invariants for output rates below the tube rate (19 750 Hz -> 16 / 11.025 / 8 kHz): the chunk's tube
     samples go through HBM behind a history of 2*pad samples and the tiled down-sampling kernel converts the outputs
-    whose read position lies in the chunk."""
+    whose read position lies in the chunk.  A short tube (13.8 / 12.2 cm: 25.1 / 28.4 kHz -> 8 kHz) is the widest converter a
+    stream takes: its tile needs more than 48 KB of LDS (round 4: such a stream was created and then failed at its first push)."""
     pd = cases.monet_default_params(rate)
+    if length is not None:
+        pd["length"] = length
     V, n = 21, sum(chunks)
     fr = cases.config3_frames(V, nframes=n).astype(np.float32)
     whole, whole_max, _ = stream_all(g, pd, fr, [n])

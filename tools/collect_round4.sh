@@ -12,6 +12,7 @@ cp $R/single_voice.txt profiles/single_voice_r04.txt
 cp $R/rates.txt profiles/rates_r04.txt
 cp $R/sweep_auto.txt profiles/sweep_forms_r04.txt
 cat $R/fuzz_parity.txt $R/fuzz_parity_broad.txt | grep -v "^seed .*oracle refuses" | tail -12 > profiles/fuzz_r04.txt
+(echo "tools/fuzz_stream.py 0 60 and 0 30 tract, TRM_TUBE_KERNEL=wide then quad (chunked == single push bit for bit, == one-shot / oracle to rounding):"; cat $R/fuzz_stream.txt) >> profiles/fuzz_r04.txt
 rm -f profiles/traffic_r04.json
 # <tag> <voices> <frames per voice (ragged: the longest)> <kind> <kernel form>
 for a in "config1 4096 251 static wide/split" "config1_whole 4096 251 static oct" "config2 4096 251 timevarying wide/split" "config3 1024 1498 ragged wide/split" "config4 8192 251 timevarying wide/split" "config4_whole 8192 251 timevarying quad" "wide65536 65536 251 static wide"; do

@@ -25,3 +25,4 @@ python tools/single_voice_latency.py > $R/single_voice.txt 2>&1; tail -6 $R/sing
 python tools/bench_rates.py > $R/rates.txt 2>&1; head -5 $R/rates.txt
 python tools/fuzz_parity.py 0 120 > $R/fuzz_parity.txt 2>&1; tail -4 $R/fuzz_parity.txt
 python tools/fuzz_parity.py 0 60 300 broad > $R/fuzz_parity_broad.txt 2>&1; tail -4 $R/fuzz_parity_broad.txt
+for f in wide quad; do TRM_TUBE_KERNEL=$f python tools/fuzz_stream.py 0 60 2>&1 | tail -1; TRM_TUBE_KERNEL=$f python tools/fuzz_stream.py 0 30 tract 2>&1 | tail -1; done > $R/fuzz_stream.txt; cat $R/fuzz_stream.txt
