@@ -65,7 +65,7 @@ EXPORTS = [
     "trm_stream_create", "trm_stream_destroy", "trm_stream_samples_for_push", "trm_stream_samples_for_finish",
     "trm_stream_push", "trm_stream_finish", "trm_stream_set_mode", "trm_stream_mode", "trm_stream_set_slice", "trm_stream_slice", "trm_stream_push_device", "trm_stream_finish_device", "trm_stream_kernel",
     "trm_events_count_frames", "trm_drift_seed_after", "trm_batch_generate_frames_device", "trm_batch_generate_frames_host",
-    "trm_batch_set_kernel", "trm_batch_last_kernel", "trm_batch_set_time_split", "trm_batch_last_time_split",
+    "trm_batch_set_kernel", "trm_batch_last_kernel", "trm_batch_set_time_split", "trm_batch_last_time_split", "trm_batch_hint_frames",
     "trm_batch_kernel_time_ms", "trm_batch_set_timing", "trm_batch_noise_table", "trm_device_count", "trm_build_info", "trm_kernel_blocks_per_cu", "trm_kernel_blocks_per_cu_form",
 ]
 
@@ -165,6 +165,7 @@ def lib():
     L.trm_batch_last_kernel.argtypes = [vp]
     L.trm_batch_set_time_split.argtypes = [vp, C.c_int]
     L.trm_batch_last_time_split.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.trm_batch_hint_frames.argtypes = [vp, vp, C.c_size_t]
     L.trm_batch_noise_table.argtypes = [vp, vp, C.c_size_t]
     for name in EXPORTS:
         getattr(L, name)

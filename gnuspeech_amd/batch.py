@@ -173,6 +173,11 @@ class TRMBatch:
         (default: torch's current stream)."""
         import torch
         s = stream if stream is not None else torch.cuda.current_stream()
+        # the lengths as the host knows them: AUTO sizes a ragged batch's segments by the work it really holds (trm_batch_hint_frames)
+        nfh = st.get("nframes_host")
+        if nfh is not None and st["V"] > 0:
+            nfh = np.ascontiguousarray(nfh, dtype=np.uint32)
+            check(lib().trm_batch_hint_frames(self._h, nfh.ctypes.data, st["V"]))
         check(lib().trm_batch_synthesize_device(
             self._h, st["V"], st["frames"].data_ptr(), st["frame_offset"].data_ptr(), st["nframes"].data_ptr(),
             st["max_nframes"], st["out"].data_ptr(), st["out_offset"].data_ptr(), st["number_samples"].data_ptr(),

@@ -110,8 +110,11 @@ struct trm_batch {
     uint32_t lastSplitPeriods = 0, lastSplitWarm = 0;      // what the last launch did (0: whole utterances)
     int lastSplitForm = TRM_KERNEL_WIDE;
     DevBuf<double> dSegPhase, dPeriodAdv;
+    DevBuf<uint2> dSegMap;               // a time-split grid's launch order (trm_seg_map_kernel)
+    DevBuf<uint32_t> dBlockFrames;
     uint32_t *dGate = nullptr;
     uint64_t hintTotalPeriods = 0;       // set by the host-buffer entries (they see every voice's length) for the launch that follows
+    std::vector<uint32_t> hintFrames;    // every voice's frame count in launch order (trm_batch_hint_frames / the host entries), for that launch
 };
 
 struct trm_tube {
@@ -466,6 +469,15 @@ static uint32_t split_segments(uint32_t P, uint32_t periods, uint32_t warm)
     return P <= first ? 1u : 1u + (P - first + periods - 1) / periods;
 }
 
+// workgroups of a time-split launch that have work: block by block (its longest voice, in control periods) the segments it
+// reaches -- what trm_seg_map_kernel counts on the device
+static uint64_t busy_workgroups(const std::vector<uint32_t> &longest, uint32_t periods, uint32_t warm)
+{
+    uint64_t n = 0;
+    for (uint32_t per : longest) n += split_segments(per, periods, warm);
+    return n;
+}
+
 // `which` = the kernel form the launch would take unsplit.  `totalPeriods` = the control periods of all voices together where
 // the caller knows them (the host-buffer entries; 0: every voice is taken to be as long as the longest).
 static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nframes, int which, int byName, uint64_t totalPeriods, SplitPlan &pl)
@@ -474,6 +486,17 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
     const int setting = b->splitSetting;
     if (setting == TRM_TIME_SPLIT_OFF || max_nframes < 2) return TRM_OK;
     const uint32_t CP = (uint32_t)b->c.controlPeriod, P = max_nframes - 1;
+    // the longest voice (in control periods) of every block of 64 / 16 voices, where the caller told the lengths
+    std::vector<uint32_t> longest64, longest16;
+    if (b->hintFrames.size() == nvoices && setting <= 0) {
+        longest64.assign((nvoices + 63) / 64, 0);
+        longest16.assign((nvoices + 15) / 16, 0);
+        for (size_t v = 0; v < nvoices; v++) {
+            const uint32_t nfr = b->hintFrames[v] < max_nframes ? b->hintFrames[v] : max_nframes, per = nfr > 0 ? nfr - 1 : 0;
+            longest64[v / 64] = longest64[v / 64] > per ? longest64[v / 64] : per;
+            longest16[v / 16] = longest16[v / 16] > per ? longest16[v / 16] : per;
+        }
+    }
     const uint32_t ws = split_warm_samples(b->c);
     if (ws == 0) {
         if (setting > 0) return fail(TRM_ERANGE, "time split: the tube never forgets (loss factor %g %%)", b->params.lossFactor);
@@ -504,14 +527,17 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
             if (sp < minPeriods) break;
             const uint64_t segs = split_segments(P, sp, warm);
             if (segs < 2) continue;
-            // workgroups: per segment the blocks of 64 voices that reach it
-            const uint64_t wgs = totalPeriods == 0 ? segs * ((nvoices + 63) / 64)
-                                                   : (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (segs + 1) / 2;      // (+ partly filled last blocks)
+            // workgroups with work: per segment the blocks of 64 voices that reach it (they are launched first:
+            // trm_seg_map_kernel) -- counted where the caller's lengths are known, else every block in every segment
+            const uint64_t wgs = !longest64.empty() ? busy_workgroups(longest64, sp, warm)
+                                 : totalPeriods == 0 ? segs * ((nvoices + 63) / 64)
+                                                     : (totalPeriods + 64ull * sp - 1) / (64ull * sp) + (segs + 1) / 2;    // (+ partly filled last blocks)
             const double t = 0.03 + wide_cost(b, wgs) * (double)(sp + warm) * CP / 19750.0;
             if (t < best) { best = t; periods = sp; pl.form = TRM_KERNEL_WIDE; }
             // ... or in the four-lane form (16 voices x one segment per workgroup, one workgroup per CU at 3.1 ms per second of
             // speech): a handful of voices, a single utterance
-            const uint64_t wgsQ = totalPeriods == 0 ? segs * ((nvoices + 15) / 16) : (totalPeriods + 16ull * sp - 1) / (16ull * sp) + (segs + 1) / 2;
+            const uint64_t wgsQ = !longest16.empty() ? busy_workgroups(longest16, sp, warm)
+                                  : totalPeriods == 0 ? segs * ((nvoices + 15) / 16) : (totalPeriods + 16ull * sp - 1) / (16ull * sp) + (segs + 1) / 2;
             if (quadOk && wgsQ <= (uint64_t)(b->cus > 0 ? b->cus : 256)) {
                 const double tq = 0.03 + 3.1 * (double)(sp + warm) * CP / 19750.0;
                 if (tq < best) { best = tq; periods = sp; pl.form = TRM_KERNEL_QUAD; }
@@ -528,6 +554,14 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
         const double t = (1.0 - r2) / (1.0 + r2);
         pl.bwFloor = (float)((double)b->d.sampleRate * atan(t) / 3.14159265358979323846);
     }
+    return TRM_OK;
+}
+
+int trm_batch_hint_frames(trm_batch *b, const uint32_t *nframes, size_t nvoices)
+{
+    if (!b) return fail(TRM_EINVAL, "null batch");
+    if (!nframes || nvoices == 0) { b->hintFrames.clear(); return TRM_OK; }
+    b->hintFrames.assign(nframes, nframes + nvoices);
     return TRM_OK;
 }
 
@@ -648,6 +682,7 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
     const int byName = b->kernel != TRM_KERNEL_AUTO ? b->kernel : b->envKernel;
     if (!(formByName && b->splitSetting <= 0) && (rc = plan_time_split(b, nvoices, max_nframes, which, byName, b->hintTotalPeriods, pl))) return rc;
     b->hintTotalPeriods = 0;                          // (a hint holds for one launch)
+    b->hintFrames.clear();
     b->lastSplitPeriods = pl.periods;
     b->lastSplitWarm = pl.periods ? pl.warm : 0;
     if (pl.periods) {
@@ -655,7 +690,8 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         const uint32_t perWg = pl.form == TRM_KERNEL_QUAD ? 16u : 64u;
         const uint32_t wgPerSeg = (uint32_t)((nvoices + perWg - 1) / perWg);
         if ((uint64_t)nseg * wgPerSeg > 0x7FFFFFFFull / 64) return fail(TRM_ERANGE, "time split: too many segments");
-        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * perWg)) || (rc = b->dPeriodAdv.reserve(nvoices * (size_t)max_nframes))) return rc;
+        if ((rc = b->dSegPhase.reserve((size_t)nseg * wgPerSeg * perWg)) || (rc = b->dPeriodAdv.reserve(nvoices * (size_t)max_nframes)) ||
+            (rc = b->dSegMap.reserve((size_t)nseg * wgPerSeg)) || (rc = b->dBlockFrames.reserve(wgPerSeg))) return rc;
         HIP_TRY(hipMemsetAsync(b->dGate, 0, sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_max_sample, 0, nvoices * sizeof(float), stream));
         trm::PhaseArgs ph;
@@ -664,11 +700,13 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         ph.nvoices = (uint32_t)nvoices; ph.max_nframes = max_nframes; ph.nseg = nseg;
         ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg; ph.seg_first = pl.periods + pl.warm;
         ph.voices_per_wg = perWg;
+        ph.seg_map = b->dSegMap.p; ph.block_frames = b->dBlockFrames.p;
         HIP_TRY(trm::launch_phase(b->c, ph, stream));
         trm::TubeArgs sa = a;
         sa.seg_periods = pl.periods; sa.seg_warm = pl.warm; sa.seg_wg_per_seg = wgPerSeg; sa.seg_grid = nseg * wgPerSeg;
         sa.seg_first = pl.periods + pl.warm;
         sa.seg_phase = b->dSegPhase.p;
+        sa.seg_map = b->dSegMap.p;
         sa.gate = b->dGate; sa.gate_want = 0;
         if (pl.form == TRM_KERNEL_QUAD) HIP_TRY(trm::launch_tube_quad(b->c, sa, stream, b->cus));
         else HIP_TRY(trm::launch_tube(b->c, sa, stream));
@@ -1221,6 +1259,8 @@ static int synthesize_host_impl(trm_batch *b, size_t nvoices, const float *frame
         bool desc = true;
         for (size_t v = 1; v < nvoices && desc && !permuted; v++) desc = nframes[v] <= nframes[v - 1];
         b->hintTotalPeriods = (permuted || desc) ? tp : 0;
+        const uint32_t *order = permuted ? pNFrames.data() : nframes;
+        b->hintFrames.assign(order, order + nvoices);
     }
     rc = trm_batch_synthesize_device(b, nvoices, b->dFrames.p, b->dFrameOff.p, b->dNFrames.p, maxFrames, b->dOut.p,
                                      b->dOutOff.p, b->dNSamples.p, b->dMax.p, s);

@@ -63,6 +63,9 @@ struct TubeArgs {
     // at once unless (*gate != 0) == gate_want.  Null: no gate.
     const uint32_t *gate = nullptr;
     uint32_t gate_want = 0;
+    // Time-split launches: workgroup w of the grid runs segment seg_map[w].x of the block of voices seg_map[w].y, the pairs
+    // that have work first (trm_seg_map_kernel).  Null: w / seg_wg_per_seg and w % seg_wg_per_seg.
+    const uint2 *seg_map = nullptr;
 };
 
 // trm_phase_*_kernel: the oscillator advances a time-split launch starts from, and the guard that decides whether the batch
@@ -78,6 +81,9 @@ struct PhaseArgs {
     float bw_floor;
     uint32_t nvoices, max_nframes, nseg, seg_periods, seg_warm, seg_wg_per_seg, seg_first;
     uint32_t voices_per_wg;       // of the tube kernel that follows: 64 (trm_tube_kernel) or 16 (trm_tube_kernel_q)
+    // the launch order of the (segment, block of voices) pairs: those with work first (null: none is built)
+    uint2 *seg_map = nullptr;
+    uint32_t *block_frames = nullptr;     // scratch, seg_wg_per_seg entries: the longest voice of every block
 };
 hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream);
 

