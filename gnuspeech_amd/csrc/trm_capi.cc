@@ -416,6 +416,7 @@ namespace {
 struct SplitPlan {
     uint32_t periods = 0;         // control periods per segment; 0 = whole utterances
     uint32_t warm = 0;            // warm-up control periods
+    bool allBusy = false;         // the caller's lengths say every workgroup of the grid has work: no launch order to build
     int form = TRM_KERNEL_WIDE;   // the segment instance that runs it: one voice per lane (64 voices per workgroup) or four lanes per voice (16)
     float bwFloor = 0.0f;         // frication bandwidths below this need a longer warm-up: the launch falls back (device-side)
 };
@@ -545,6 +546,10 @@ static int plan_time_split(const trm_batch *b, size_t nvoices, uint32_t max_nfra
         }
     }
     if (periods == 0 || split_segments(P, periods, warm) < 2) return TRM_OK;      // one segment is the whole utterance
+    {
+        const std::vector<uint32_t> &longest = pl.form == TRM_KERNEL_QUAD ? longest16 : longest64;
+        pl.allBusy = !longest.empty() && busy_workgroups(longest, periods, warm) == (uint64_t)split_segments(P, periods, warm) * longest.size();
+    }
     pl.periods = periods;
     pl.warm = warm;
     {
@@ -700,13 +705,13 @@ int trm_batch_synthesize_device(trm_batch *b, size_t nvoices, const float *d_fra
         ph.nvoices = (uint32_t)nvoices; ph.max_nframes = max_nframes; ph.nseg = nseg;
         ph.seg_periods = pl.periods; ph.seg_warm = pl.warm; ph.seg_wg_per_seg = wgPerSeg; ph.seg_first = pl.periods + pl.warm;
         ph.voices_per_wg = perWg;
-        ph.seg_map = b->dSegMap.p; ph.block_frames = b->dBlockFrames.p;
+        ph.seg_map = pl.allBusy ? nullptr : b->dSegMap.p; ph.block_frames = b->dBlockFrames.p;
         HIP_TRY(trm::launch_phase(b->c, ph, stream));
         trm::TubeArgs sa = a;
         sa.seg_periods = pl.periods; sa.seg_warm = pl.warm; sa.seg_wg_per_seg = wgPerSeg; sa.seg_grid = nseg * wgPerSeg;
         sa.seg_first = pl.periods + pl.warm;
         sa.seg_phase = b->dSegPhase.p;
-        sa.seg_map = b->dSegMap.p;
+        sa.seg_map = ph.seg_map;
         sa.gate = b->dGate; sa.gate_want = 0;
         if (pl.form == TRM_KERNEL_QUAD) HIP_TRY(trm::launch_tube_quad(b->c, sa, stream, b->cus));
         else HIP_TRY(trm::launch_tube(b->c, sa, stream));

@@ -730,14 +730,12 @@ __global__ __launch_bounds__(256) void trm_phase_segment_kernel(const Const C, c
 // the pairs with work in (segment, block) order and the others after them.
 __global__ __launch_bounds__(256) void trm_seg_blocks_kernel(const PhaseArgs P)
 {
-    const uint32_t blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= P.seg_wg_per_seg) return;
-    uint32_t longest = 0;
-    for (uint32_t i = 0; i < P.voices_per_wg; i++) {
-        const uint32_t v = blk * P.voices_per_wg + i;
-        if (v < P.nvoices) longest = max(longest, min(P.nframes[v], P.max_nframes));
-    }
-    P.block_frames[blk] = longest;
+    // thread = voice; a block's 64 (or 16) voices are neighbouring lanes of one wave
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t longest = v < P.nvoices ? min(P.nframes[v], P.max_nframes) : 0u;
+    for (uint32_t off = P.voices_per_wg >> 1; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, (int)off, kWave));
+    const uint32_t blk = v / P.voices_per_wg;
+    if ((v & (P.voices_per_wg - 1)) == 0 && blk < P.seg_wg_per_seg) P.block_frames[blk] = longest;
 }
 
 constexpr int kMapThreads = 1024;
@@ -1097,7 +1095,7 @@ hipError_t launch_phase(const Const &c, const PhaseArgs &a, hipStream_t stream)
     const uint64_t threads = (uint64_t)(a.nseg - 1) * a.seg_wg_per_seg * a.voices_per_wg;
     if (threads > 0) hipLaunchKernelGGL(trm_phase_segment_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, c, a);
     if (a.seg_map && a.block_frames) {
-        hipLaunchKernelGGL(trm_seg_blocks_kernel, dim3((a.seg_wg_per_seg + 255) / 256), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(trm_seg_blocks_kernel, dim3((a.seg_wg_per_seg * a.voices_per_wg + 255) / 256), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(trm_seg_map_kernel, dim3(1), dim3(kMapThreads), 0, stream, a);
     }
     return hipGetLastError();
